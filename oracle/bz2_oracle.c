@@ -1,0 +1,709 @@
+/*
+ * bz2_oracle.c -- CPU restatement of the bastie/bzip2 block compressor (see bz2_oracle.h).
+ * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (no runnable reference artefact exists).
+ *
+ * "S/" = /root/reference/Sources/bzip2JavApi/.  Semantics follow the Java-original statements
+ * kept in the Swift files' comments: 32-bit signed int arithmetic, uint16 MTF symbols.
+ */
+#include "bz2_oracle.h"
+
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ CRC32 */
+/* S/BZip2CRC32.swift:32-66: table of poly 0x04c11db7, MSB first (generated, not copied). */
+static uint32_t crc_table[256];
+static int crc_table_ready = 0;
+
+static void crc_init(void) {
+    if (crc_table_ready) return;
+    for (uint32_t i = 0; i < 256; i++) {
+        uint32_t c = i << 24;
+        for (int k = 0; k < 8; k++) c = (c & 0x80000000u) ? (c << 1) ^ 0x04c11db7u : (c << 1);
+        crc_table[i] = c;
+    }
+    crc_table_ready = 1;
+}
+
+/* S/BZip2CRC32.swift:84-88 */
+uint32_t orc_crc32_update(uint32_t crc, const uint8_t *p, size_t n) {
+    crc_init();
+    for (size_t i = 0; i < n; i++) crc = (crc << 8) ^ crc_table[((crc >> 24) ^ p[i]) & 0xff];
+    return crc;
+}
+
+/* ------------------------------------------------------------------ RLE1 */
+typedef struct {
+    uint8_t *block;
+    int block_len;
+    int limit;
+    uint8_t *present;
+    uint32_t crc;
+    int rle_value;
+    int rle_len;
+} rle1_t;
+
+/* S/BZip2BlockCompressor.swift:151-191 */
+static void rle1_write_run(rle1_t *s, int value, int run) {
+    s->present[value] = 1;
+    for (int i = 0; i < run; i++) /* S/BZip2CRC32.swift:95-105 */
+        s->crc = (s->crc << 8) ^ crc_table[((s->crc >> 24) ^ (uint32_t)value) & 0xff];
+    uint8_t *b = s->block + s->block_len;
+    switch (run) {
+    case 1: b[0] = (uint8_t)value; s->block_len += 1; break;
+    case 2: b[0] = b[1] = (uint8_t)value; s->block_len += 2; break;
+    case 3: b[0] = b[1] = b[2] = (uint8_t)value; s->block_len += 3; break;
+    default:
+        run -= 4;
+        s->present[run] = 1;
+        b[0] = b[1] = b[2] = b[3] = (uint8_t)value;
+        b[4] = (uint8_t)run;
+        s->block_len += 5;
+        break;
+    }
+}
+
+/* S/BZip2BlockCompressor.swift:198-227 */
+static int rle1_write(rle1_t *s, int value) {
+    if (s->block_len > s->limit) return 0;
+    if (s->rle_len == 0) {
+        s->rle_value = value;
+        s->rle_len = 1;
+    } else if (s->rle_value != value) {
+        rle1_write_run(s, s->rle_value & 0xff, s->rle_len);
+        s->rle_value = value;
+        s->rle_len = 1;
+    } else {
+        if (s->rle_len == 254) {
+            rle1_write_run(s, s->rle_value & 0xff, 255);
+            s->rle_len = 0;
+        } else {
+            s->rle_len++;
+        }
+    }
+    return 1;
+}
+
+size_t orc_rle1_block(const uint8_t *in, size_t n_in, int block_size, uint8_t *block,
+                      int *block_len, uint8_t present[256], uint32_t *block_crc) {
+    crc_init();
+    rle1_t s;
+    s.block = block;
+    s.block_len = 0;
+    s.limit = block_size - 6; /* S/BZip2BlockCompressor.swift:319 */
+    s.present = present;
+    memset(present, 0, 256);
+    s.crc = 0xffffffffu;
+    s.rle_value = -1;
+    s.rle_len = 0;
+    size_t i = 0;
+    while (i < n_in && rle1_write(&s, in[i])) i++; /* :237-252 */
+    if (s.rle_len > 0) rle1_write_run(&s, s.rle_value & 0xff, s.rle_len); /* :261-263 */
+    if (s.block_len > 0) block[s.block_len] = block[0];                   /* :266 */
+    *block_len = s.block_len;
+    *block_crc = ~s.crc; /* S/BZip2CRC32.swift:76-78 */
+    return i;
+}
+
+/* ------------------------------------------------------------------ BWT (tier 1) */
+static int g_tie_rule = 0;
+void orc_set_tie_rule(int rule) { g_tie_rule = rule; }
+
+void orc_bwt(const uint8_t *T, int n, uint8_t *bwt, int *orig, int *periodic) {
+    if (periodic) *periodic = 1;
+    *orig = 0;
+    if (n == 0) return; /* S/BZip2DivSufSort.swift:3494-3495 */
+    if (n == 1) {       /* :3496-3499 */
+        bwt[0] = T[0];
+        return;
+    }
+    int *sa = (int *)malloc(sizeof(int) * (size_t)n);
+    int *tmp = (int *)malloc(sizeof(int) * (size_t)n);
+    int *rank = (int *)malloc(sizeof(int) * (size_t)n);
+    int *nrank = (int *)malloc(sizeof(int) * (size_t)n);
+    int *next = (int *)malloc(sizeof(int) * (size_t)(n > 256 ? n : 256));
+    /* depth 1: counting sort by first byte; rank = head position of the group */
+    int cnt[257];
+    memset(cnt, 0, sizeof(cnt));
+    for (int i = 0; i < n; i++) cnt[T[i] + 1]++;
+    for (int c = 0; c < 256; c++) cnt[c + 1] += cnt[c];
+    for (int c = 0; c < 256; c++) next[c] = cnt[c];
+    for (int i = 0; i < n; i++) {
+        rank[i] = cnt[T[i]];
+        sa[next[T[i]]++] = i;
+    }
+    int groups = 0;
+    for (int c = 0; c < 256; c++) groups += (cnt[c + 1] > cnt[c]);
+    long h = 1;
+    while (groups < n && h < n) {
+        /* sa is ordered by the depth-h prefix.  Enumerate i = sa[j]-h (mod n) => i in order of
+         * rank[(i+h) mod n]; stable-bucket by rank[i] (bucket start == rank value). */
+        for (int j = 0; j < n; j++) next[j] = j; /* only head positions are used */
+        int hh = (int)(h % n);
+        for (int j = 0; j < n; j++) {
+            int i = sa[j] - hh;
+            if (i < 0) i += n;
+            tmp[next[rank[i]]++] = i;
+        }
+        groups = 0;
+        int head = 0;
+        for (int j = 0; j < n; j++) {
+            int i = tmp[j];
+            if (j == 0) {
+                head = 0;
+                groups = 1;
+            } else {
+                int p = tmp[j - 1];
+                int i2 = i + hh; if (i2 >= n) i2 -= n;
+                int p2 = p + hh; if (p2 >= n) p2 -= n;
+                if (rank[i] != rank[p] || rank[i2] != rank[p2]) {
+                    head = j;
+                    groups++;
+                }
+            }
+            nrank[i] = head;
+        }
+        int *t = sa; sa = tmp; tmp = t;
+        t = rank; rank = nrank; nrank = t;
+        h <<= 1;
+    }
+    for (int j = 0; j < n; j++) {
+        int i = sa[j] - 1;
+        if (i < 0) i += n;
+        bwt[j] = T[i];
+    }
+    int k = 1;
+    if (groups < n) k = n / groups; /* block == w^k: every class has exactly k members */
+    if (periodic) *periodic = k;
+    int o = rank[0];
+    if (k > 1 && k < n) {
+        /* tie rule for periodic blocks (DESIGN.md "orig on periodic blocks") */
+        if (g_tie_rule == 1) o += k - 1;
+    }
+    if (k == n) o = 0; /* all-equal: S/BZip2DivSufSort.swift:3168-3174,3505 */
+    *orig = o;
+    free(sa); free(tmp); free(rank); free(nrank); free(next);
+}
+
+static const uint8_t *g_bf_T;
+static int g_bf_n;
+static int bf_cmp(const void *a, const void *b) {
+    int i = *(const int *)a, j = *(const int *)b;
+    int c = memcmp(g_bf_T + i, g_bf_T + j, (size_t)g_bf_n);
+    if (c) return c;
+    return (i > j) - (i < j);
+}
+
+void orc_bwt_bruteforce(const uint8_t *T, int n, uint8_t *bwt, int *orig_first, int *orig_last) {
+    *orig_first = *orig_last = 0;
+    if (n == 0) return;
+    uint8_t *TT = (uint8_t *)malloc((size_t)n * 2);
+    memcpy(TT, T, (size_t)n);
+    memcpy(TT + n, T, (size_t)n);
+    int *sa = (int *)malloc(sizeof(int) * (size_t)n);
+    for (int i = 0; i < n; i++) sa[i] = i;
+    g_bf_T = TT;
+    g_bf_n = n;
+    qsort(sa, (size_t)n, sizeof(int), bf_cmp);
+    int first = -1, last = -1;
+    for (int j = 0; j < n; j++) {
+        bwt[j] = TT[sa[j] + n - 1];
+        if (memcmp(TT + sa[j], TT, (size_t)n) == 0) {
+            if (first < 0) first = j;
+            last = j;
+        }
+    }
+    *orig_first = first;
+    *orig_last = last;
+    free(sa);
+    free(TT);
+}
+
+/* ------------------------------------------------------------------ MTF + RLE2 */
+/* S/BZip2MoveToFront.swift:66-82 */
+static int mtf_value_to_front(uint8_t *mtf, uint8_t value) {
+    int index = 0;
+    uint8_t temp = mtf[0];
+    if (value != temp) {
+        mtf[0] = value;
+        while (value != temp) {
+            index++;
+            uint8_t temp2 = temp;
+            temp = mtf[index];
+            mtf[index] = temp2;
+        }
+    }
+    return index;
+}
+
+/* BZip2MTFAndRLE2StageEncoder.java:85-98 */
+static int emit_run(uint16_t *mtf, int idx, int repeat, int *run_a, int *run_b) {
+    repeat--;
+    for (;;) {
+        if ((repeat & 1) == 0) { mtf[idx++] = 0; (*run_a)++; }
+        else                   { mtf[idx++] = 1; (*run_b)++; }
+        if (repeat <= 1) break;
+        repeat = (int)(((uint32_t)(repeat - 2)) >> 1);
+    }
+    return idx;
+}
+
+void orc_mtf_rle2(const uint8_t *bwt, int n, const uint8_t present[256], uint16_t *mtf,
+                  int *mtf_len, int *alpha, int32_t freq[ORC_MAX_ALPHA]) {
+    uint8_t map[256];
+    uint8_t list[256];
+    memset(map, 0, sizeof(map));
+    memset(freq, 0, sizeof(int32_t) * ORC_MAX_ALPHA);
+    for (int i = 0; i < 256; i++) list[i] = (uint8_t)i; /* S/BZip2MoveToFront.swift:34-58 */
+    int unique = 0;
+    for (int i = 0; i < 256; i++) /* java:60-65 */
+        if (present[i]) map[i] = (uint8_t)unique++;
+    int eob = unique + 1; /* java:67 */
+    int idx = 0, repeat = 0, run_a = 0, run_b = 0;
+    for (int i = 0; i < n; i++) { /* java:74-106 */
+        int pos = mtf_value_to_front(list, map[bwt[i]]);
+        if (pos == 0) {
+            repeat++;
+        } else {
+            if (repeat > 0) {
+                idx = emit_run(mtf, idx, repeat, &run_a, &run_b);
+                repeat = 0;
+            }
+            mtf[idx++] = (uint16_t)(pos + 1);
+            freq[pos + 1]++;
+        }
+    }
+    if (repeat > 0) idx = emit_run(mtf, idx, repeat, &run_a, &run_b); /* java:108-124 */
+    mtf[idx] = (uint16_t)eob; /* java:126-129 */
+    freq[eob]++;
+    freq[0] += run_a;
+    freq[1] += run_b;
+    *mtf_len = idx + 1; /* java:131-132 */
+    *alpha = eob + 1;
+}
+
+/* ------------------------------------------------------------------ Huffman allocator */
+/* S/BZip2HuffmanAllocator.swift:44-66 */
+static int ha_first(const int32_t *a, int len, int i, int nodes_to_move) {
+    int limit = i;
+    int k = len - 2;
+    while (i >= nodes_to_move && (a[i] % len) > limit) {
+        k = i;
+        i -= (limit - i + 1);
+    }
+    i = (nodes_to_move - 1 > i) ? nodes_to_move - 1 : i;
+    while (k > i + 1) {
+        int temp = (i + k) >> 1;
+        if ((a[temp] % len) > limit) k = temp; else i = temp;
+    }
+    return k;
+}
+
+/* S/BZip2HuffmanAllocator.swift:72-104 */
+static void ha_set_extended_parent_pointers(int32_t *a, int len) {
+    a[0] += a[1];
+    int head = 0, tail = 1, top = 2;
+    while (tail < len - 1) {
+        int32_t temp;
+        if (top >= len || a[head] < a[top]) { temp = a[head]; a[head++] = tail; }
+        else                                { temp = a[top++]; }
+        if (top >= len || (head < tail && a[head] < a[top])) { temp += a[head]; a[head++] = tail + len; }
+        else                                                 { temp += a[top++]; }
+        a[tail++] = temp;
+    }
+}
+
+/* S/BZip2HuffmanAllocator.swift:112-122 */
+static int ha_find_nodes_to_relocate(const int32_t *a, int len, int max_len) {
+    int node = len - 2;
+    for (int depth = 1; depth < max_len - 1 && node > 1; depth++) node = ha_first(a, len, node - 1, 0);
+    return node;
+}
+
+/* S/BZip2HuffmanAllocator.swift:128-147 with the Java for-header */
+static void ha_allocate_node_lengths(int32_t *a, int len) {
+    int first_node = len - 2, next_node = len - 1;
+    for (int depth = 1, avail = 2; avail > 0; depth++) {
+        int last_node = first_node;
+        first_node = ha_first(a, len, last_node - 1, 0);
+        for (int i = avail - (last_node - first_node); i > 0; i--) a[next_node--] = depth;
+        avail = (last_node - first_node) << 1;
+    }
+}
+
+/* S/BZip2HuffmanAllocator.swift:155-189 with the Java for-header kept at :164 */
+static void ha_allocate_node_lengths_with_relocation(int32_t *a, int len, int nodes_to_move,
+                                                     int insert_depth) {
+    int first_node = len - 2, next_node = len - 1;
+    int depth = (insert_depth == 1) ? 2 : 1;
+    int left = (insert_depth == 1) ? nodes_to_move - 2 : nodes_to_move;
+    for (int avail = depth << 1; avail > 0; depth++) {
+        int last_node = first_node;
+        first_node = (first_node <= nodes_to_move) ? first_node
+                                                   : ha_first(a, len, last_node - 1, nodes_to_move);
+        int offset = 0;
+        if (depth >= insert_depth) {
+            int lim = 1 << (depth - insert_depth);
+            offset = left < lim ? left : lim;
+        } else if (depth == insert_depth - 1) {
+            offset = 1;
+            if (a[first_node] == last_node) first_node++;
+        }
+        for (int i = avail - (last_node - first_node + offset); i > 0; i--) a[next_node--] = depth;
+        left -= offset;
+        avail = (last_node - first_node + offset) << 1;
+    }
+}
+
+/* S/BZip2HuffmanAllocator.swift:197-223 */
+void orc_huffman_allocate(int32_t *a, int len, int max_len) {
+    if (len == 2) { a[1] = 1; a[0] = 1; return; } /* Java switch fall-through */
+    if (len == 1) { a[0] = 1; return; }
+    ha_set_extended_parent_pointers(a, len);
+    int r = ha_find_nodes_to_relocate(a, len, max_len);
+    if ((a[0] % len) >= r) {
+        ha_allocate_node_lengths(a, len);
+    } else {
+        int insert_depth = max_len - (32 - __builtin_clz((unsigned)(r - 1))); /* SURVEY D11 */
+        ha_allocate_node_lengths_with_relocation(a, len, r, insert_depth);
+    }
+}
+
+static int cmp_i32(const void *a, const void *b) {
+    int32_t x = *(const int32_t *)a, y = *(const int32_t *)b;
+    return (x > y) - (x < y);
+}
+
+/* S/BZip2HuffmanStageEncoder.swift:107-135 */
+void orc_huffman_code_lengths(int alpha, const int32_t *freq, int32_t *lengths) {
+    int32_t merged[ORC_MAX_ALPHA], sorted[ORC_MAX_ALPHA];
+    for (int i = 0; i < alpha; i++) merged[i] = (freq[i] << 9) | i;
+    qsort(merged, (size_t)alpha, sizeof(int32_t), cmp_i32);
+    for (int i = 0; i < alpha; i++) sorted[i] = (int32_t)(((uint32_t)merged[i]) >> 9);
+    orc_huffman_allocate(sorted, alpha, 20); /* S/BZip2Constants.swift:52 */
+    for (int i = 0; i < alpha; i++) lengths[merged[i] & 0x1ff] = sorted[i];
+}
+
+/* ------------------------------------------------------------------ Huffman stage */
+/* S/BZip2HuffmanStageEncoder.swift:82-98 */
+static int select_table_count(int mtf_len) {
+    if (mtf_len >= 2400) return 6;
+    if (mtf_len >= 1200) return 5;
+    if (mtf_len >= 600) return 4;
+    if (mtf_len >= 200) return 3;
+    return 2;
+}
+
+int orc_huffman_optimise(const uint16_t *mtf, int mtf_len, int alpha, const int32_t *freq,
+                         int32_t lengths[ORC_MAX_TABLES][ORC_MAX_ALPHA], uint8_t *selectors,
+                         int *n_selectors, int32_t *iter_lengths) {
+    int tables = select_table_count(mtf_len);
+    memset(lengths, 0, sizeof(int32_t) * ORC_MAX_TABLES * ORC_MAX_ALPHA);
+    /* seeds: S/BZip2HuffmanStageEncoder.swift:144-181 */
+    int remaining = mtf_len, low_end = -1;
+    for (int i = 0; i < tables; i++) {
+        int target = remaining / (tables - i);
+        int low_start = low_end + 1;
+        int actual = 0;
+        while (actual < target && low_end < alpha - 1) actual += freq[++low_end];
+        if (low_end > low_start && i != 0 && i != tables - 1 && ((tables - i) & 1) == 0)
+            actual -= freq[low_end--];
+        for (int j = 0; j < alpha; j++)
+            if (j < low_start || j > low_end) lengths[i][j] = 15;
+        remaining -= actual;
+    }
+    /* 4 passes: :360-366, body :192-248 */
+    static __thread int32_t tfreq[ORC_MAX_TABLES][ORC_MAX_ALPHA];
+    int nsel = 0;
+    for (int pass = 3; pass >= 0; pass--) {
+        memset(tfreq, 0, sizeof(tfreq));
+        int sel = 0;
+        for (int gs = 0; gs < mtf_len;) {
+            int ge = (gs + ORC_GROUP < mtf_len ? gs + ORC_GROUP : mtf_len) - 1;
+            int16_t cost[ORC_MAX_TABLES] = {0, 0, 0, 0, 0, 0};
+            for (int i = gs; i <= ge; i++) {
+                int v = mtf[i];
+                for (int j = 0; j < tables; j++) cost[j] = (int16_t)(cost[j] + lengths[j][v]);
+            }
+            int best = 0, best_cost = cost[0];
+            for (int j = 1; j < tables; j++)
+                if (cost[j] < best_cost) { best_cost = cost[j]; best = j; }
+            for (int i = gs; i <= ge; i++) tfreq[best][mtf[i]]++;
+            if (pass == 0) selectors[sel] = (uint8_t)best;
+            sel++;
+            gs = ge + 1;
+        }
+        nsel = sel;
+        for (int j = 0; j < tables; j++) orc_huffman_code_lengths(alpha, tfreq[j], lengths[j]);
+        if (iter_lengths)
+            memcpy(iter_lengths + (size_t)(3 - pass) * ORC_MAX_TABLES * ORC_MAX_ALPHA, lengths,
+                   sizeof(int32_t) * ORC_MAX_TABLES * ORC_MAX_ALPHA);
+    }
+    *n_selectors = nsel;
+    return tables;
+}
+
+/* S/BZip2HuffmanStageEncoder.swift:254-287 */
+void orc_huffman_codes(int n_tables, int alpha, int32_t lengths[ORC_MAX_TABLES][ORC_MAX_ALPHA],
+                       int32_t merged[ORC_MAX_TABLES][ORC_MAX_ALPHA]) {
+    for (int t = 0; t < n_tables; t++) {
+        int mn = 32, mx = 0;
+        for (int j = 0; j < alpha; j++) {
+            int l = lengths[t][j];
+            if (l > mx) mx = l;
+            if (l < mn) mn = l;
+        }
+        int code = 0;
+        for (int l = mn; l <= mx; l++) {
+            for (int k = 0; k < alpha; k++)
+                if ((lengths[t][k] & 0xff) == l) merged[t][k] = (l << 24) | code++;
+            code <<= 1;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ bit writer */
+/* S/BZip2BitOutputStream.swift:53-120 (32-bit accumulator semantics: only the low `count`
+ * bits of value reach the stream) */
+typedef struct {
+    uint8_t *p;
+    uint64_t acc;
+    int nb;
+    uint64_t total;
+} bw_t;
+
+static void bw_init(bw_t *w, uint8_t *p) { w->p = p; w->acc = 0; w->nb = 0; w->total = 0; }
+
+static inline void bw_bits(bw_t *w, int count, uint32_t value) {
+    if (count == 0) return;
+    value &= (count >= 32) ? 0xffffffffu : ((1u << count) - 1u);
+    w->acc = (w->acc << count) | value;
+    w->nb += count;
+    w->total += (uint64_t)count;
+    while (w->nb >= 8) {
+        *w->p++ = (uint8_t)(w->acc >> (w->nb - 8));
+        w->nb -= 8;
+    }
+}
+static inline void bw_bool(bw_t *w, int v) { bw_bits(w, 1, v ? 1u : 0u); }
+static inline void bw_int(bw_t *w, uint32_t v) { bw_bits(w, 16, v >> 16); bw_bits(w, 16, v & 0xffff); }
+static void bw_unary(bw_t *w, int v) { while (v-- > 0) bw_bool(w, 1); bw_bool(w, 0); }
+/* leaves partial byte (left-aligned, zero padded) at *p without advancing: flush semantic */
+static void bw_flush(bw_t *w) {
+    if (w->nb > 0) { *w->p++ = (uint8_t)(w->acc << (8 - w->nb)); w->nb = 0; }
+}
+static void bw_append(bw_t *w, const uint8_t *src, uint64_t nbits) {
+    uint64_t full = nbits >> 3;
+    for (uint64_t i = 0; i < full; i++) bw_bits(w, 8, src[i]);
+    int rem = (int)(nbits & 7);
+    if (rem) bw_bits(w, rem, (uint32_t)(src[full] >> (8 - rem)));
+}
+
+/* ------------------------------------------------------------------ block */
+size_t orc_block_bound(int n) { return (size_t)n + (size_t)n / 2 + 40000; }
+
+/* S/BZip2BlockCompressor.swift:258-289 (after RLE1) */
+static void block_encode(bw_t *w, const uint8_t *block, int n, const uint8_t present[256],
+                         uint32_t crc) {
+    uint8_t *bwt = (uint8_t *)malloc((size_t)n + 1);
+    uint16_t *mtf = (uint16_t *)malloc(sizeof(uint16_t) * ((size_t)n + 2));
+    uint8_t *selectors = (uint8_t *)malloc(ORC_MAX_SELECTORS + 8);
+    int orig, per;
+    orc_bwt(block, n, bwt, &orig, &per);
+    /* header :273-277 */
+    bw_bits(w, 24, 0x314159);
+    bw_bits(w, 24, 0x265359);
+    bw_int(w, crc);
+    bw_bool(w, 0);
+    bw_bits(w, 24, (uint32_t)orig);
+    /* symbol map :89-144 */
+    int used16[16];
+    for (int i = 0; i < 16; i++) {
+        used16[i] = 0;
+        for (int k = 0; k < 16; k++) if (present[i * 16 + k]) used16[i] = 1;
+    }
+    for (int i = 0; i < 16; i++) bw_bool(w, used16[i]);
+    for (int i = 0; i < 16; i++)
+        if (used16[i]) for (int k = 0; k < 16; k++) bw_bool(w, present[i * 16 + k]);
+    /* MTF/RLE2 :283-284 */
+    int mtf_len, alpha;
+    int32_t freq[ORC_MAX_ALPHA];
+    orc_mtf_rle2(bwt, n, present, mtf, &mtf_len, &alpha, freq);
+    /* Huffman :287-288 */
+    static __thread int32_t lengths[ORC_MAX_TABLES][ORC_MAX_ALPHA];
+    static __thread int32_t merged[ORC_MAX_TABLES][ORC_MAX_ALPHA];
+    int nsel;
+    int tables = orc_huffman_optimise(mtf, mtf_len, alpha, freq, lengths, selectors, &nsel, NULL);
+    orc_huffman_codes(tables, alpha, lengths, merged);
+    /* S/BZip2HuffmanStageEncoder.swift:294-329 */
+    bw_bits(w, 3, (uint32_t)tables);
+    bw_bits(w, 15, (uint32_t)nsel);
+    uint8_t sel_mtf[256];
+    for (int i = 0; i < 256; i++) sel_mtf[i] = (uint8_t)i;
+    for (int i = 0; i < nsel; i++) bw_unary(w, mtf_value_to_front(sel_mtf, selectors[i]));
+    for (int t = 0; t < tables; t++) {
+        int cur = lengths[t][0];
+        bw_bits(w, 5, (uint32_t)cur);
+        for (int j = 0; j < alpha; j++) {
+            int len = lengths[t][j];
+            uint32_t v = (cur < len) ? 2u : 3u;
+            int delta = len > cur ? len - cur : cur - len;
+            while (delta-- > 0) bw_bits(w, 2, v);
+            bw_bool(w, 0);
+            cur = len;
+        }
+    }
+    /* :336-353 */
+    int sel = 0;
+    for (int i = 0; i < mtf_len;) {
+        int ge = (i + ORC_GROUP < mtf_len ? i + ORC_GROUP : mtf_len) - 1;
+        const int32_t *m = merged[selectors[sel++]];
+        for (; i <= ge; i++) {
+            uint32_t mc = (uint32_t)m[mtf[i]];
+            bw_bits(w, (int)(mc >> 24), mc);
+        }
+    }
+    free(bwt); free(mtf); free(selectors);
+}
+
+uint64_t orc_block_compress(const uint8_t *rle_block, int n, const uint8_t present[256],
+                            uint32_t block_crc, uint8_t *bits) {
+    bw_t w;
+    bw_init(&w, bits);
+    block_encode(&w, rle_block, n, present, block_crc);
+    uint64_t total = w.total;
+    bw_flush(&w);
+    return total;
+}
+
+/* ------------------------------------------------------------------ stream */
+size_t orc_compress_bound(size_t n) { return n + n / 4 + 70000 + (n / 100000 + 1) * 2100; }
+
+static int valid_level(int level) { return level >= 1 && level <= 9; }
+
+size_t orc_compress(const uint8_t *in, size_t n, int level, uint8_t *out, size_t cap,
+                    int *n_blocks) {
+    if (!valid_level(level)) return 0; /* S/BZip2OutputStream.swift:173-175 */
+    if (cap < orc_compress_bound(n)) return 0;
+    crc_init();
+    int bs = level * 100000; /* :177 */
+    bw_t w;
+    bw_init(&w, out);
+    bw_bits(&w, 16, 0x425a); /* :181-184 */
+    bw_bits(&w, 8, 0x68);
+    bw_bits(&w, 8, (uint32_t)('0' + level));
+    uint8_t *block = (uint8_t *)malloc((size_t)bs + 8);
+    uint8_t present[256];
+    uint32_t stream_crc = 0;
+    size_t pos = 0;
+    int blocks = 0;
+    while (pos < n) {
+        int blen;
+        uint32_t crc;
+        pos += orc_rle1_block(in + pos, n - pos, bs, block, &blen, present, &crc);
+        if (blen == 0) break; /* isEmpty :133-135 (cannot happen with pos < n) */
+        block_encode(&w, block, blen, present, crc);
+        stream_crc = ((stream_crc << 1) | (stream_crc >> 31)) ^ crc; /* :139 */
+        blocks++;
+    }
+    bw_bits(&w, 24, 0x177245); /* :154-157 */
+    bw_bits(&w, 24, 0x385090);
+    bw_int(&w, stream_crc);
+    bw_flush(&w);
+    free(block);
+    if (n_blocks) *n_blocks = blocks;
+    return (size_t)(w.p - out);
+}
+
+int orc_split(const uint8_t *in, size_t n, int level, uint64_t *starts, int max) {
+    if (!valid_level(level)) return -1;
+    crc_init();
+    int bs = level * 100000;
+    uint8_t *block = (uint8_t *)malloc((size_t)bs + 8);
+    uint8_t present[256];
+    size_t pos = 0;
+    int blocks = 0;
+    while (pos < n) {
+        int blen;
+        uint32_t crc;
+        if (blocks < max) starts[blocks] = pos;
+        pos += orc_rle1_block(in + pos, n - pos, bs, block, &blen, present, &crc);
+        blocks++;
+    }
+    free(block);
+    return blocks;
+}
+
+typedef struct {
+    const uint8_t *in;
+    size_t n;
+    int bs;
+    const uint64_t *starts;
+    int n_blocks;
+    int next;
+    pthread_mutex_t mu;
+    uint8_t **bits;
+    uint64_t *nbits;
+    uint32_t *crcs;
+} mt_job_t;
+
+static void *mt_worker(void *arg) {
+    mt_job_t *J = (mt_job_t *)arg;
+    uint8_t *block = (uint8_t *)malloc((size_t)J->bs + 8);
+    for (;;) {
+        pthread_mutex_lock(&J->mu);
+        int b = J->next++;
+        pthread_mutex_unlock(&J->mu);
+        if (b >= J->n_blocks) break;
+        size_t s = J->starts[b];
+        size_t e = (b + 1 < J->n_blocks) ? J->starts[b + 1] : J->n;
+        uint8_t present[256];
+        int blen;
+        uint32_t crc;
+        orc_rle1_block(J->in + s, e - s, J->bs, block, &blen, present, &crc);
+        J->bits[b] = (uint8_t *)calloc(1, orc_block_bound(blen));
+        J->nbits[b] = orc_block_compress(block, blen, present, crc, J->bits[b]);
+        J->crcs[b] = crc;
+    }
+    free(block);
+    return NULL;
+}
+
+size_t orc_compress_mt(const uint8_t *in, size_t n, int level, uint8_t *out, size_t cap,
+                       int threads, int *n_blocks) {
+    if (!valid_level(level)) return 0;
+    if (cap < orc_compress_bound(n)) return 0;
+    int max_blocks = (int)(n / (size_t)(level * 80000)) + 16;
+    uint64_t *starts = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)max_blocks);
+    int nb = orc_split(in, n, level, starts, max_blocks);
+    mt_job_t J;
+    J.in = in; J.n = n; J.bs = level * 100000; J.starts = starts; J.n_blocks = nb; J.next = 0;
+    pthread_mutex_init(&J.mu, NULL);
+    J.bits = (uint8_t **)calloc((size_t)nb + 1, sizeof(uint8_t *));
+    J.nbits = (uint64_t *)calloc((size_t)nb + 1, sizeof(uint64_t));
+    J.crcs = (uint32_t *)calloc((size_t)nb + 1, sizeof(uint32_t));
+    if (threads < 1) threads = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
+    for (int i = 0; i < threads; i++) pthread_create(&th[i], NULL, mt_worker, &J);
+    for (int i = 0; i < threads; i++) pthread_join(th[i], NULL);
+    bw_t w;
+    bw_init(&w, out);
+    bw_bits(&w, 16, 0x425a);
+    bw_bits(&w, 8, 0x68);
+    bw_bits(&w, 8, (uint32_t)('0' + level));
+    uint32_t stream_crc = 0;
+    for (int b = 0; b < nb; b++) {
+        bw_append(&w, J.bits[b], J.nbits[b]);
+        stream_crc = ((stream_crc << 1) | (stream_crc >> 31)) ^ J.crcs[b];
+        free(J.bits[b]);
+    }
+    bw_bits(&w, 24, 0x177245);
+    bw_bits(&w, 24, 0x385090);
+    bw_int(&w, stream_crc);
+    bw_flush(&w);
+    free(J.bits); free(J.nbits); free(J.crcs); free(th); free(starts);
+    pthread_mutex_destroy(&J.mu);
+    if (n_blocks) *n_blocks = nb;
+    return (size_t)(w.p - out);
+}

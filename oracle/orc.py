@@ -1,0 +1,208 @@
+"""ctypes loader for the CPU oracle (oracle/libbz2oracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package (bzip2_amd) must never import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libbz2oracle.so")
+
+MAX_ALPHA = 258
+MAX_TABLES = 6
+
+
+def build(force=False):
+    if force or not os.path.exists(_SO) or (
+        os.path.exists(os.path.join(_HERE, "bz2_oracle.c"))
+        and os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "bz2_oracle.c"))
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        u8p = C.POINTER(C.c_uint8)
+        L.orc_crc32_update.restype = C.c_uint32
+        L.orc_crc32_update.argtypes = [C.c_uint32, C.c_void_p, C.c_size_t]
+        L.orc_rle1_block.restype = C.c_size_t
+        L.orc_rle1_block.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p,
+                                     C.POINTER(C.c_int), C.c_void_p, C.POINTER(C.c_uint32)]
+        L.orc_bwt.restype = None
+        L.orc_bwt.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_bwt_bruteforce.restype = None
+        L.orc_bwt_bruteforce.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int),
+                                         C.POINTER(C.c_int)]
+        L.orc_mtf_rle2.restype = None
+        L.orc_mtf_rle2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int),
+                                   C.POINTER(C.c_int), C.c_void_p]
+        L.orc_huffman_allocate.restype = None
+        L.orc_huffman_allocate.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_huffman_code_lengths.restype = None
+        L.orc_huffman_code_lengths.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_huffman_optimise.restype = C.c_int
+        L.orc_huffman_optimise.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
+        L.orc_huffman_codes.restype = None
+        L.orc_huffman_codes.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_block_compress.restype = C.c_uint64
+        L.orc_block_compress.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_block_bound.restype = C.c_size_t
+        L.orc_block_bound.argtypes = [C.c_int]
+        L.orc_compress.restype = C.c_size_t
+        L.orc_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t,
+                                   C.POINTER(C.c_int)]
+        L.orc_compress_mt.restype = C.c_size_t
+        L.orc_compress_mt.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t,
+                                      C.c_int, C.POINTER(C.c_int)]
+        L.orc_compress_bound.restype = C.c_size_t
+        L.orc_compress_bound.argtypes = [C.c_size_t]
+        L.orc_split.restype = C.c_int
+        L.orc_split.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_int]
+        L.orc_set_tie_rule.restype = None
+        L.orc_set_tie_rule.argtypes = [C.c_int]
+        _lib = L
+    return _lib
+
+
+def _u8(a):
+    a = np.ascontiguousarray(np.frombuffer(a, dtype=np.uint8) if isinstance(a, (bytes, bytearray)) else a,
+                             dtype=np.uint8)
+    return a
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def crc32(data, crc=0xFFFFFFFF):
+    a = _u8(data)
+    return lib().orc_crc32_update(crc, _ptr(a), a.size)
+
+
+def block_crc(data):
+    return (~crc32(data)) & 0xFFFFFFFF
+
+
+def rle1_block(data, block_size):
+    """-> (consumed, block bytes (np.uint8[n]), present (np.uint8[256]), crc)"""
+    a = _u8(data)
+    block = np.zeros(block_size + 8, dtype=np.uint8)
+    present = np.zeros(256, dtype=np.uint8)
+    blen = C.c_int(0)
+    crc = C.c_uint32(0)
+    consumed = lib().orc_rle1_block(_ptr(a), a.size, block_size, _ptr(block), C.byref(blen),
+                                    _ptr(present), C.byref(crc))
+    return consumed, block[: blen.value].copy(), present, crc.value
+
+
+def bwt(block):
+    """-> (bwt bytes, orig, period count k)"""
+    a = _u8(block)
+    out = np.zeros(max(a.size, 1), dtype=np.uint8)
+    orig = C.c_int(0)
+    per = C.c_int(0)
+    lib().orc_bwt(_ptr(a), a.size, _ptr(out), C.byref(orig), C.byref(per))
+    return out[: a.size], orig.value, per.value
+
+
+def bwt_bruteforce(block):
+    a = _u8(block)
+    out = np.zeros(max(a.size, 1), dtype=np.uint8)
+    f = C.c_int(0)
+    l = C.c_int(0)
+    lib().orc_bwt_bruteforce(_ptr(a), a.size, _ptr(out), C.byref(f), C.byref(l))
+    return out[: a.size], f.value, l.value
+
+
+def mtf_rle2(bwt_bytes, present):
+    a = _u8(bwt_bytes)
+    p = _u8(present)
+    mtf = np.zeros(a.size + 2, dtype=np.uint16)
+    freq = np.zeros(MAX_ALPHA, dtype=np.int32)
+    ml = C.c_int(0)
+    al = C.c_int(0)
+    lib().orc_mtf_rle2(_ptr(a), a.size, _ptr(p), _ptr(mtf), C.byref(ml), C.byref(al), _ptr(freq))
+    return mtf[: ml.value].copy(), al.value, freq
+
+
+def huffman_allocate(sorted_freq, max_len=20):
+    a = np.ascontiguousarray(sorted_freq, dtype=np.int32).copy()
+    lib().orc_huffman_allocate(_ptr(a), a.size, max_len)
+    return a
+
+
+def huffman_code_lengths(freq, alpha):
+    f = np.ascontiguousarray(freq, dtype=np.int32)
+    out = np.zeros(MAX_ALPHA, dtype=np.int32)
+    lib().orc_huffman_code_lengths(alpha, _ptr(f), _ptr(out))
+    return out[:alpha]
+
+
+def huffman_optimise(mtf, alpha, freq, want_iters=False):
+    """-> (n_tables, lengths[6][258], selectors[, iter_lengths[4][6][258]])"""
+    m = np.ascontiguousarray(mtf, dtype=np.uint16)
+    f = np.ascontiguousarray(freq, dtype=np.int32)
+    lengths = np.zeros((MAX_TABLES, MAX_ALPHA), dtype=np.int32)
+    sel = np.zeros((m.size + 49) // 50 + 8, dtype=np.uint8)
+    nsel = C.c_int(0)
+    it = np.zeros((4, MAX_TABLES, MAX_ALPHA), dtype=np.int32) if want_iters else None
+    nt = lib().orc_huffman_optimise(_ptr(m), m.size, alpha, _ptr(f), _ptr(lengths), _ptr(sel),
+                                    C.byref(nsel), _ptr(it) if want_iters else None)
+    if want_iters:
+        return nt, lengths, sel[: nsel.value].copy(), it
+    return nt, lengths, sel[: nsel.value].copy()
+
+
+def huffman_codes(n_tables, alpha, lengths):
+    l = np.ascontiguousarray(lengths, dtype=np.int32)
+    merged = np.zeros((MAX_TABLES, MAX_ALPHA), dtype=np.int32)
+    lib().orc_huffman_codes(n_tables, alpha, _ptr(l), _ptr(merged))
+    return merged
+
+
+def block_compress(rle_block, present, crc):
+    """-> (bytes holding the bits, nbits)"""
+    a = _u8(rle_block)
+    p = _u8(present)
+    out = np.zeros(lib().orc_block_bound(a.size), dtype=np.uint8)
+    nbits = lib().orc_block_compress(_ptr(a), a.size, _ptr(p), crc, _ptr(out))
+    return out[: (nbits + 7) // 8].copy(), nbits
+
+
+def compress(data, level=9, threads=1):
+    a = _u8(data)
+    cap = lib().orc_compress_bound(a.size)
+    out = np.zeros(cap, dtype=np.uint8)
+    nb = C.c_int(0)
+    if threads <= 1:
+        n = lib().orc_compress(_ptr(a), a.size, level, _ptr(out), cap, C.byref(nb))
+    else:
+        n = lib().orc_compress_mt(_ptr(a), a.size, level, _ptr(out), cap, threads, C.byref(nb))
+    if n == 0:
+        raise ValueError("oracle compress failed (bad level or capacity)")
+    return out[:n].tobytes(), nb.value
+
+
+def split(data, level=9):
+    a = _u8(data)
+    mx = a.size // (level * 80000) + 16
+    starts = np.zeros(mx, dtype=np.uint64)
+    nb = lib().orc_split(_ptr(a), a.size, level, _ptr(starts), mx)
+    return starts[:nb].copy()
+
+
+def set_tie_rule(rule):
+    lib().orc_set_tie_rule(rule)
