@@ -1,0 +1,264 @@
+"""ctypes binding of libbz2hip.so (the C ABI in include/bz2hip.h).
+
+The product path: there is NO CPU fallback.  If the HIP library is missing or no GPU is
+present, every compute entry point raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "csrc", "libbz2hip.so")
+
+OK, E_PARAM, E_NOMEM, E_HIP, E_CAP, E_STATE = 0, -1, -2, -3, -4, -5
+MAX_ALPHA, MAX_TABLES = 258, 6
+
+# every symbol include/bz2hip.h declares
+SYMBOLS = [
+    "bz2hip_create", "bz2hip_destroy", "bz2hip_last_error", "bz2hip_version",
+    "bz2hip_compress_bound", "bz2hip_compress", "bz2hip_compress_device",
+    "bz2hip_stream_begin", "bz2hip_stream_write", "bz2hip_stream_finish", "bz2hip_stream_read",
+    "bz2hip_stream_pending", "bz2hip_rle1_split", "bz2hip_bwt", "bz2hip_mtf_rle2",
+    "bz2hip_huffman", "bz2hip_block_compress", "bz2hip_profile_reset", "bz2hip_profile_get",
+    "bz2hip_last_stats",
+]
+
+
+class Opts(C.Structure):
+    _fields_ = [("device", C.c_int), ("max_batch_blocks", C.c_int), ("tie_rule", C.c_int),
+                ("profile", C.c_int)]
+
+
+class BZ2HipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"bz2hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Loads libbz2hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise ImportError(f"{SO_PATH} missing: build it with `make -C bzip2_amd/csrc` "
+                          "(there is no CPU fallback)")
+    L = C.CDLL(SO_PATH)
+    vp, sz, u32p = C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)
+    L.bz2hip_create.restype = C.c_int
+    L.bz2hip_create.argtypes = [C.POINTER(vp), C.POINTER(Opts)]
+    L.bz2hip_destroy.restype = None
+    L.bz2hip_destroy.argtypes = [vp]
+    L.bz2hip_last_error.restype = C.c_char_p
+    L.bz2hip_last_error.argtypes = [vp]
+    L.bz2hip_version.restype = C.c_char_p
+    L.bz2hip_compress_bound.restype = sz
+    L.bz2hip_compress_bound.argtypes = [sz]
+    L.bz2hip_compress.restype = C.c_int
+    L.bz2hip_compress.argtypes = [vp, vp, sz, C.c_int, vp, sz, C.POINTER(sz)]
+    L.bz2hip_compress_device.restype = C.c_int
+    L.bz2hip_compress_device.argtypes = [vp, vp, sz, C.c_int, vp, sz, C.POINTER(sz)]
+    L.bz2hip_stream_begin.restype = C.c_int
+    L.bz2hip_stream_begin.argtypes = [vp, C.c_int]
+    L.bz2hip_stream_write.restype = C.c_int
+    L.bz2hip_stream_write.argtypes = [vp, vp, sz]
+    L.bz2hip_stream_finish.restype = C.c_int
+    L.bz2hip_stream_finish.argtypes = [vp]
+    L.bz2hip_stream_read.restype = C.c_int
+    L.bz2hip_stream_read.argtypes = [vp, vp, sz, C.POINTER(sz)]
+    L.bz2hip_stream_pending.restype = sz
+    L.bz2hip_stream_pending.argtypes = [vp]
+    L.bz2hip_rle1_split.restype = C.c_int
+    L.bz2hip_rle1_split.argtypes = [vp, vp, sz, C.c_int, C.c_uint32, u32p, vp, vp, vp, vp, vp]
+    L.bz2hip_bwt.restype = C.c_int
+    L.bz2hip_bwt.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp]
+    L.bz2hip_mtf_rle2.restype = C.c_int
+    L.bz2hip_mtf_rle2.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp]
+    L.bz2hip_huffman.restype = C.c_int
+    L.bz2hip_huffman.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp,
+                                 C.c_uint32, vp]
+    L.bz2hip_block_compress.restype = C.c_int
+    L.bz2hip_block_compress.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, sz, vp]
+    L.bz2hip_profile_reset.restype = C.c_int
+    L.bz2hip_profile_reset.argtypes = [vp]
+    L.bz2hip_profile_get.restype = C.c_int
+    L.bz2hip_profile_get.argtypes = [vp, C.POINTER(C.c_int), vp, vp, vp, vp]
+    L.bz2hip_last_stats.restype = C.c_int
+    L.bz2hip_last_stats.argtypes = [vp, vp, vp, vp, vp]
+    _lib = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One GPU compression context (bz2hip_ctx)."""
+
+    def __init__(self, device=-1, max_batch_blocks=0, tie_rule=0, profile=False):
+        self.L = load()
+        self.h = C.c_void_p()
+        o = Opts(device, max_batch_blocks, tie_rule, 1 if profile else 0)
+        rc = self.L.bz2hip_create(C.byref(self.h), C.byref(o))
+        if rc != OK:
+            raise BZ2HipError(rc, "bz2hip_create failed (no GPU / HIP runtime?)")
+
+    def close(self):
+        if self.h:
+            self.L.bz2hip_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise BZ2HipError(rc, self.L.bz2hip_last_error(self.h).decode())
+
+    # ---- whole stream
+    def compress(self, data, level=9):
+        a = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else \
+            np.ascontiguousarray(data, dtype=np.uint8)
+        cap = self.L.bz2hip_compress_bound(a.size)
+        out = np.empty(cap, dtype=np.uint8)
+        n = C.c_size_t(0)
+        self._chk(self.L.bz2hip_compress(self.h, _p(a), a.size, level, _p(out), cap, C.byref(n)))
+        return out[: n.value].tobytes()
+
+    def compress_device(self, d_in_ptr, n, level, d_out_ptr, cap):
+        got = C.c_size_t(0)
+        self._chk(self.L.bz2hip_compress_device(self.h, C.c_void_p(d_in_ptr), n, level,
+                                                C.c_void_p(d_out_ptr), cap, C.byref(got)))
+        return got.value
+
+    # ---- streaming
+    def stream_begin(self, level):
+        self._chk(self.L.bz2hip_stream_begin(self.h, level))
+
+    def stream_write(self, data):
+        a = np.frombuffer(bytes(data), dtype=np.uint8)
+        self._chk(self.L.bz2hip_stream_write(self.h, _p(a), a.size))
+
+    def stream_finish(self):
+        self._chk(self.L.bz2hip_stream_finish(self.h))
+
+    def stream_read(self, cap=1 << 20):
+        out = np.empty(cap, dtype=np.uint8)
+        n = C.c_size_t(0)
+        self._chk(self.L.bz2hip_stream_read(self.h, _p(out), cap, C.byref(n)))
+        return out[: n.value].tobytes()
+
+    def stream_pending(self):
+        return self.L.bz2hip_stream_pending(self.h)
+
+    # ---- stages (batched, host arrays)
+    def rle1_split(self, data, level):
+        a = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else \
+            np.ascontiguousarray(data, dtype=np.uint8)
+        bs = level * 100000
+        mx = a.size // (level * 50000) + 8
+        nb = C.c_uint32(0)
+        starts = np.zeros(mx, dtype=np.uint64)
+        rle = np.zeros((mx, bs + 8), dtype=np.uint8)
+        rlen = np.zeros(mx, dtype=np.uint32)
+        present = np.zeros((mx, 256), dtype=np.uint8)
+        crc = np.zeros(mx, dtype=np.uint32)
+        self._chk(self.L.bz2hip_rle1_split(self.h, _p(a), a.size, level, mx, C.byref(nb),
+                                           _p(starts), _p(rle), _p(rlen), _p(present), _p(crc)))
+        k = nb.value
+        return starts[:k], [rle[b, : rlen[b]].copy() for b in range(k)], present[:k], crc[:k]
+
+    def bwt(self, blocks):
+        """blocks: list of uint8 arrays -> list of (bwt, orig, rounds)"""
+        count = len(blocks)
+        stride = max(max(len(b) for b in blocks), 1)
+        T = np.zeros((count, stride), dtype=np.uint8)
+        n = np.zeros(count, dtype=np.uint32)
+        for i, b in enumerate(blocks):
+            T[i, : len(b)] = np.frombuffer(bytes(b), dtype=np.uint8) if not isinstance(b, np.ndarray) else b
+            n[i] = len(b)
+        out = np.zeros((count, stride), dtype=np.uint8)
+        orig = np.zeros(count, dtype=np.uint32)
+        rounds = np.zeros(count, dtype=np.uint32)
+        self._chk(self.L.bz2hip_bwt(self.h, _p(T), _p(n), count, stride, _p(out), _p(orig), _p(rounds)))
+        return [(out[i, : n[i]].copy(), int(orig[i]), int(rounds[i])) for i in range(count)]
+
+    def mtf_rle2(self, bwts, presents):
+        count = len(bwts)
+        stride = max(max(len(b) for b in bwts), 1)
+        T = np.zeros((count, stride), dtype=np.uint8)
+        n = np.zeros(count, dtype=np.uint32)
+        for i, b in enumerate(bwts):
+            T[i, : len(b)] = b
+            n[i] = len(b)
+        pres = np.ascontiguousarray(np.stack(presents), dtype=np.uint8)
+        mtf = np.zeros((count, stride + 2), dtype=np.uint16)
+        ml = np.zeros(count, dtype=np.uint32)
+        al = np.zeros(count, dtype=np.uint32)
+        freq = np.zeros((count, 258), dtype=np.int32)
+        self._chk(self.L.bz2hip_mtf_rle2(self.h, _p(T), _p(n), count, stride, _p(pres), _p(mtf),
+                                         _p(ml), _p(al), _p(freq)))
+        return [(mtf[i, : ml[i]].copy(), int(al[i]), freq[i].copy()) for i in range(count)]
+
+    def huffman(self, mtfs, alphas, freqs):
+        count = len(mtfs)
+        stride = max(len(m) for m in mtfs)
+        M = np.zeros((count, stride), dtype=np.uint16)
+        ml = np.zeros(count, dtype=np.uint32)
+        for i, m in enumerate(mtfs):
+            M[i, : len(m)] = m
+            ml[i] = len(m)
+        al = np.asarray(alphas, dtype=np.uint32)
+        fr = np.ascontiguousarray(np.stack(freqs), dtype=np.int32)
+        nt = np.zeros(count, dtype=np.uint32)
+        lengths = np.zeros((count, 6, 258), dtype=np.int32)
+        ss = 18048
+        sel = np.zeros((count, ss), dtype=np.uint8)
+        ns = np.zeros(count, dtype=np.uint32)
+        self._chk(self.L.bz2hip_huffman(self.h, _p(M), _p(ml), _p(al), _p(fr), count, stride,
+                                        _p(nt), _p(lengths), _p(sel), ss, _p(ns)))
+        return [(int(nt[i]), lengths[i].copy(), sel[i, : ns[i]].copy()) for i in range(count)]
+
+    def block_compress(self, blocks, presents, crcs):
+        count = len(blocks)
+        stride = max(len(b) for b in blocks)
+        T = np.zeros((count, stride), dtype=np.uint8)
+        n = np.zeros(count, dtype=np.uint32)
+        for i, b in enumerate(blocks):
+            T[i, : len(b)] = b
+            n[i] = len(b)
+        pres = np.ascontiguousarray(np.stack(presents), dtype=np.uint8)
+        crc = np.asarray(crcs, dtype=np.uint32)
+        bstride = (stride + stride // 2 + 40000 + 3) & ~3
+        bits = np.zeros((count, bstride), dtype=np.uint8)
+        nbits = np.zeros(count, dtype=np.uint64)
+        self._chk(self.L.bz2hip_block_compress(self.h, _p(T), _p(n), count, stride, _p(pres),
+                                               _p(crc), _p(bits), bstride, _p(nbits)))
+        return [(bits[i, : (int(nbits[i]) + 7) // 8].copy(), int(nbits[i])) for i in range(count)]
+
+    # ---- profiling
+    def profile_reset(self):
+        self.L.bz2hip_profile_reset(self.h)
+
+    def profile_get(self):
+        cnt = C.c_int(0)
+        names = (C.c_char_p * 48)()
+        ms = (C.c_double * 48)()
+        launches = (C.c_uint64 * 48)()
+        ab = (C.c_double * 48)()
+        self.L.bz2hip_profile_get(self.h, C.byref(cnt), names, ms, launches, ab)
+        return {names[i].decode(): {"ms": ms[i], "launches": launches[i]} for i in range(cnt.value)}
+
+    def last_stats(self):
+        v = [C.c_uint64(0) for _ in range(4)]
+        self.L.bz2hip_last_stats(self.h, *[C.byref(x) for x in v])
+        return {"blocks": v[0].value, "rounds_sum": v[1].value, "rle_bytes": v[2].value,
+                "periodic_blocks": v[3].value}

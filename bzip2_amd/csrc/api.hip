@@ -1,0 +1,653 @@
+// api.hip -- C ABI of libbz2hip (include/bz2hip.h): context, workspace, pipeline drivers.
+#include "ctx.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+#define WMAX (1u << 30) // window of input scanned at once (u32 prefix sums stay < 2^32)
+
+// ------------------------------------------------------------------ workspace
+template <typename T>
+static T *dalloc(bz2hip_ctx *c, size_t count) {
+    void *p = nullptr;
+    size_t bytes = std::max<size_t>(count * sizeof(T), 256);
+    HIPCHK(hipMalloc(&p, bytes));
+    c->allocs.push_back(p);
+    c->batch.bytes += bytes;
+    return (T *)p;
+}
+
+static void dfree_all(bz2hip_ctx *c) {
+    for (void *p : c->allocs) (void)hipFree(p);
+    c->allocs.clear();
+    c->batch = Batch();
+}
+
+static void ensure_batch(bz2hip_ctx *c, int level, int nb_needed) {
+    Batch &B = c->batch;
+    const u32 S = (u32)(((size_t)level * 100000 + 8 + RTILE - 1) / RTILE * RTILE);
+    int cap = c->opts.max_batch_blocks > 0 ? c->opts.max_batch_blocks : 256;
+    int want = std::min(cap, std::max(nb_needed, 1));
+    if (B.NB >= want && B.S == S) return;
+    want = std::max(want, B.S == S ? B.NB : 0);
+    // free the old batch (window scratch is tracked separately)
+    dfree_all(c);
+    Batch &N = c->batch;
+    N.NB = want;
+    N.S = S;
+    N.TPB = S / RTILE;
+    const size_t nb = (size_t)want;
+    const size_t S2 = S + 64;
+    N.T = dalloc<u8>(c, nb * S);
+    N.n = dalloc<u32>(c, nb);
+    N.present = dalloc<u32>(c, nb * 8);
+    N.crc = dalloc<u32>(c, nb);
+    N.keyA = dalloc<u64>(c, nb * S);
+    N.keyB = dalloc<u64>(c, nb * S);
+    N.valA = dalloc<u32>(c, nb * S);
+    N.valB = dalloc<u32>(c, nb * S);
+    N.rank = dalloc<u32>(c, nb * S);
+    N.grp = dalloc<u32>(c, nb * S);
+    N.sa = dalloc<u32>(c, nb * S);
+    N.tilehist = dalloc<u32>(c, nb * N.TPB * 256);
+    N.digitbase = dalloc<u32>(c, nb * 256);
+    N.tileagg = dalloc<u32>(c, nb * N.TPB);
+    N.nheads = dalloc<u32>(c, nb);
+    N.active = dalloc<u32>(c, nb);
+    N.rounds = dalloc<u32>(c, nb);
+    N.ctl = dalloc<u32>(c, 64);
+    N.bwt = dalloc<u8>(c, nb * S);
+    N.orig = dalloc<u32>(c, nb);
+    N.periodic = dalloc<u32>(c, nb);
+    N.mtfrec = dalloc<u8>(c, nb * (S / MTF_CHUNK) * 256);
+    N.mtfcnt = dalloc<u32>(c, nb * (S / MTF_CHUNK));
+    N.mtfpos = dalloc<u8>(c, nb * S);
+    N.r2agg = dalloc<u32>(c, nb * N.TPB * 4);
+    N.mtf = dalloc<u16>(c, nb * S2);
+    N.mtflen = dalloc<u32>(c, nb);
+    N.alpha = dalloc<u32>(c, nb);
+    N.freq = dalloc<u32>(c, nb * 264);
+    N.ntables = dalloc<u32>(c, nb);
+    N.hlen = dalloc<u8>(c, nb * MAX_TABLES * 264);
+    N.hpart = dalloc<u32>(c, nb * HS_PART_MAX * MAX_TABLES * 264);
+    N.hfreq = dalloc<u32>(c, nb * MAX_TABLES * 264);
+    N.hcode = dalloc<u32>(c, nb * MAX_TABLES * 264);
+    N.sel = dalloc<u8>(c, nb * SEL_STRIDE);
+    N.selpos = dalloc<u8>(c, nb * SEL_STRIDE);
+    N.nsel = dalloc<u32>(c, nb);
+    N.tblbits = dalloc<u64>(c, nb * MAX_TABLES * 2);
+    N.hdrbits = dalloc<u64>(c, nb * 4);
+    N.bitoff = dalloc<u64>(c, 2 * (nb + 1));
+    N.pkagg = dalloc<u32>(c, nb * ((S2 + PK_TILE - 1) / PK_TILE));
+    HIPCHK(hipMemsetAsync(N.ctl, 0, 64 * sizeof(u32), c->stream));
+}
+
+static void wfree(bz2hip_ctx *c) {
+    u32 **ps[] = {&c->w_rs, &c->w_P, &c->w_agg1, &c->w_agg2, &c->w_starts, &c->w_eagg};
+    for (auto pp : ps) {
+        if (*pp) (void)hipFree(*pp);
+        *pp = nullptr;
+    }
+    c->w_cap = 0;
+    c->w_eagg_nb = 0;
+}
+
+static u32 window_max_blocks(size_t wlen, int level) {
+    return (u32)(wlen / ((size_t)level * 50000) + 4);
+}
+
+static void ensure_window(bz2hip_ctx *c, size_t wlen, int level) {
+    const u32 bs = (u32)level * 100000u;
+    const u32 ETPB = (u32)(((u64)bs * 52 + 2048) / 4096 + 2);
+    const u32 mb = window_max_blocks(wlen, level);
+    if (c->w_cap < wlen || c->w_maxblocks < mb) {
+        u32 **ps[] = {&c->w_rs, &c->w_P, &c->w_agg1, &c->w_agg2, &c->w_starts};
+        for (auto pp : ps) {
+            if (*pp) (void)hipFree(*pp);
+            *pp = nullptr;
+        }
+        const size_t tiles = (wlen + 4095) / 4096 + 2;
+        HIPCHK(hipMalloc((void **)&c->w_rs, (wlen + 16) * sizeof(u32)));
+        HIPCHK(hipMalloc((void **)&c->w_P, (wlen + 16) * sizeof(u32)));
+        HIPCHK(hipMalloc((void **)&c->w_agg1, tiles * sizeof(u32)));
+        HIPCHK(hipMalloc((void **)&c->w_agg2, tiles * sizeof(u32)));
+        HIPCHK(hipMalloc((void **)&c->w_starts, ((size_t)mb + 8) * sizeof(u32)));
+        c->w_cap = wlen;
+        c->w_maxblocks = mb;
+    }
+    if (c->w_eagg_nb < c->batch.NB || c->w_ETPB != ETPB) {
+        if (c->w_eagg) (void)hipFree(c->w_eagg);
+        c->w_eagg = nullptr;
+        HIPCHK(hipMalloc((void **)&c->w_eagg, (size_t)c->batch.NB * ETPB * sizeof(u32)));
+        c->w_eagg_nb = c->batch.NB;
+        c->w_ETPB = ETPB;
+    }
+}
+
+static void ensure_staging(bz2hip_ctx *c, size_t in_bytes, size_t out_bytes) {
+    if (c->h_in_cap < in_bytes) {
+        if (c->h_in) (void)hipFree(c->h_in);
+        c->h_in = nullptr;
+        HIPCHK(hipMalloc((void **)&c->h_in, in_bytes + 64));
+        c->h_in_cap = in_bytes;
+    }
+    if (c->h_out_cap < out_bytes) {
+        if (c->h_out) (void)hipFree(c->h_out);
+        c->h_out = nullptr;
+        HIPCHK(hipMalloc((void **)&c->h_out, out_bytes + 64));
+        c->h_out_cap = out_bytes;
+    }
+}
+
+// ------------------------------------------------------------------ error plumbing
+template <typename F>
+static int guarded(bz2hip_ctx *c, F f) {
+    if (!c) return BZ2HIP_E_PARAM;
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        return f();
+    } catch (const HipError &e) {
+        c->err = e.what();
+        (void)hipGetLastError();
+        return e.code;
+    } catch (const std::bad_alloc &) {
+        c->err = "host allocation failed";
+        return BZ2HIP_E_NOMEM;
+    } catch (const std::exception &e) {
+        c->err = e.what();
+        return BZ2HIP_E_HIP;
+    }
+}
+
+static int fail(bz2hip_ctx *c, int code, const char *msg) {
+    c->err = msg;
+    return code;
+}
+
+// ------------------------------------------------------------------ life cycle
+extern "C" const char *bz2hip_version(void) { return "bz2hip 0.1 (gfx950)"; }
+
+extern "C" size_t bz2hip_compress_bound(size_t n) {
+    return n + n / 4 + 4096 + (n / 100000 + 1) * 2600;
+}
+
+extern "C" int bz2hip_create(bz2hip_ctx **out, const bz2hip_opts *opts) {
+    if (!out) return BZ2HIP_E_PARAM;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return BZ2HIP_E_HIP;
+    bz2hip_ctx *c = new (std::nothrow) bz2hip_ctx();
+    if (!c) return BZ2HIP_E_NOMEM;
+    if (opts) c->opts = *opts;
+    else { c->opts.device = -1; c->opts.max_batch_blocks = 0; c->opts.tie_rule = 0; c->opts.profile = 0; }
+    int dev = c->opts.device;
+    if (dev < 0) {
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    }
+    if (dev >= ndev) { delete c; return BZ2HIP_E_PARAM; }
+    c->device = dev;
+    c->profile = c->opts.profile != 0;
+    if (hipSetDevice(dev) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
+        delete c;
+        return BZ2HIP_E_HIP;
+    }
+    try {
+        k1_init_tables(c);
+    } catch (const std::exception &) {
+        hipStreamDestroy(c->stream);
+        delete c;
+        return BZ2HIP_E_HIP;
+    }
+    *out = c;
+    return BZ2HIP_OK;
+}
+
+extern "C" void bz2hip_destroy(bz2hip_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    dfree_all(c);
+    wfree(c);
+    if (c->h_in) (void)hipFree(c->h_in);
+    if (c->h_out) (void)hipFree(c->h_out);
+    for (auto &r : c->prof_pending) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" const char *bz2hip_last_error(const bz2hip_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+// ------------------------------------------------------------------ the pipeline
+// Compresses blocks of d_in[0..n) into d_out (zeroed by the caller up to out_cap) starting at
+// bit *bitpos.  Only complete blocks are taken unless `final`.  Returns bytes consumed.
+static size_t compress_core(bz2hip_ctx *c, const u8 *d_in, size_t n, int level, u8 *d_out,
+                            size_t out_cap, u64 *bitpos, u32 *stream_crc, bool header, bool final) {
+    const u32 bs = (u32)level * 100000u;
+    size_t pos = 0;
+    bool wrote_header = !header;
+    c->st_blocks = c->st_rounds = c->st_rle_bytes = c->st_periodic = 0;
+    std::vector<u32> starts;
+    bool any_frame = false;
+    while (pos < n) {
+        const size_t wlen = std::min<size_t>(n - pos, WMAX);
+        const bool last_window = (pos + wlen == n);
+        ensure_batch(c, level, (int)std::min<size_t>(wlen / (bs - 4) + 1, 1u << 20));
+        ensure_window(c, wlen, level);
+        u32 cnt = run_split(c, d_in + pos, (u32)wlen, level, c->w_rs, c->w_P, c->w_agg1, c->w_agg2,
+                            c->w_starts, c->w_maxblocks, starts);
+        // a block that ends at the window end is complete only if this is the final data
+        u32 usable = cnt;
+        if (!(last_window && final) && cnt > 0 && starts[cnt] == (u32)wlen) usable = cnt - 1;
+        if (usable == 0) {
+            if (last_window) break; // leave the tail for the next call
+            throw HipError(BZ2HIP_E_HIP, "window holds no complete block");
+        }
+        Batch &B = c->batch;
+        for (u32 b0 = 0; b0 < usable; b0 += (u32)B.NB) {
+            const int nb = (int)std::min<u32>((u32)B.NB, usable - b0);
+            u32 max_in = 0;
+            for (int b = 0; b < nb; b++) max_in = std::max(max_in, starts[b0 + b + 1] - starts[b0 + b]);
+            run_rle1_emit(c, d_in + pos, c->w_rs, c->w_starts, b0, nb, max_in, c->w_eagg, c->w_ETPB);
+            run_bwt_n(c, nb, bs);
+            run_mtf(c, nb, bs);
+            run_huffman(c, nb, bs + 1);
+            run_pack(c, nb, bs + 1, d_out, *bitpos, false, 0, out_cap, nullptr);
+            const bool is_last = final && last_window && (b0 + nb == usable);
+            u64 endbit;
+            u32 crc_out;
+            run_frame(c, nb, d_out, level, !wrote_header, is_last, *stream_crc, &endbit, &crc_out);
+            wrote_header = true;
+            any_frame = true;
+            *bitpos = endbit;
+            *stream_crc = crc_out;
+            // stats
+            std::vector<u32> hr(nb), hp(nb), hn(nb);
+            HIPCHK(hipMemcpy(hr.data(), B.rounds, nb * sizeof(u32), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(hp.data(), B.periodic, nb * sizeof(u32), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(hn.data(), B.n, nb * sizeof(u32), hipMemcpyDeviceToHost));
+            for (int b = 0; b < nb; b++) {
+                c->st_blocks++;
+                c->st_rounds += hr[b];
+                c->st_rle_bytes += hn[b];
+                if (hp[b] > 1) c->st_periodic++;
+            }
+        }
+        pos += starts[usable];
+        if (usable < cnt && last_window) break;
+    }
+    if (final && !any_frame) {
+        // empty input (or nothing left): header and/or trailer only
+        ensure_batch(c, level, 1);
+        u64 bp = *bitpos;
+        HIPCHK(hipMemcpyAsync(c->batch.bitoff, &bp, sizeof(u64), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        u64 endbit;
+        u32 crc_out;
+        run_frame(c, 0, d_out, level, !wrote_header, true, *stream_crc, &endbit, &crc_out);
+        *bitpos = endbit;
+        *stream_crc = crc_out;
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->profile) c->prof_collect();
+    return pos;
+}
+
+extern "C" int bz2hip_compress_device(bz2hip_ctx *c, const void *d_in, size_t n, int level,
+                                      void *d_out, size_t cap, size_t *out_len) {
+    return guarded(c, [&]() -> int {
+        if (level < 1 || level > 9) return fail(c, BZ2HIP_E_PARAM, "Invalid BZip2 block size");
+        if (!d_out || !out_len || (n && !d_in)) return fail(c, BZ2HIP_E_PARAM, "null pointer");
+        if (((uintptr_t)d_out & 3) != 0) return fail(c, BZ2HIP_E_PARAM, "d_out must be 4-byte aligned");
+        if (cap < 64) return fail(c, BZ2HIP_E_CAP, "output buffer too small");
+        size_t zlen = std::min(cap, bz2hip_compress_bound(n)) & ~(size_t)3;
+        HIPCHK(hipMemsetAsync(d_out, 0, zlen, c->stream));
+        u64 bitpos = 32;
+        u32 scrc = 0;
+        compress_core(c, (const u8 *)d_in, n, level, (u8 *)d_out, zlen, &bitpos, &scrc, true, true);
+        *out_len = (size_t)((bitpos + 7) / 8);
+        return BZ2HIP_OK;
+    });
+}
+
+extern "C" int bz2hip_compress(bz2hip_ctx *c, const uint8_t *in, size_t n, int level, uint8_t *out,
+                               size_t cap, size_t *out_len) {
+    return guarded(c, [&]() -> int {
+        if (level < 1 || level > 9) return fail(c, BZ2HIP_E_PARAM, "Invalid BZip2 block size");
+        if (!out || !out_len || (n && !in)) return fail(c, BZ2HIP_E_PARAM, "null pointer");
+        size_t bound = bz2hip_compress_bound(n);
+        ensure_staging(c, n, bound);
+        if (n) HIPCHK(hipMemcpyAsync(c->h_in, in, n, hipMemcpyHostToDevice, c->stream));
+        size_t got = 0;
+        int rc = bz2hip_compress_device(c, c->h_in, n, level, c->h_out, bound, &got);
+        if (rc != BZ2HIP_OK) return rc;
+        if (got > cap) return fail(c, BZ2HIP_E_CAP, "output buffer too small");
+        HIPCHK(hipMemcpy(out, c->h_out, got, hipMemcpyDeviceToHost));
+        *out_len = got;
+        return BZ2HIP_OK;
+    });
+}
+
+// ------------------------------------------------------------------ streaming
+#define STREAM_CHUNK ((size_t)64 << 20)
+
+extern "C" int bz2hip_stream_begin(bz2hip_ctx *c, int level) {
+    if (!c) return BZ2HIP_E_PARAM;
+    if (level < 1 || level > 9) return fail(c, BZ2HIP_E_PARAM, "Invalid BZip2 block size");
+    c->s_level = level;
+    c->s_open = true;
+    c->s_finished = false;
+    c->s_in.clear();
+    c->s_out.clear();
+    c->s_out_pos = 0;
+    c->s_stream_crc = 0;
+    c->s_bitbuf = 0;
+    c->s_bitcnt = -1; // -1: stream header not written yet
+    // stream header is produced by the first flush (or by finish on empty input)
+    return BZ2HIP_OK;
+}
+
+// compress what is buffered; only complete blocks unless final
+static int stream_flush(bz2hip_ctx *c, bool final) {
+    return guarded(c, [&]() -> int {
+        const size_t n = c->s_in.size();
+        size_t bound = bz2hip_compress_bound(n) + 16;
+        ensure_staging(c, n, bound);
+        if (n) HIPCHK(hipMemcpyAsync(c->h_in, c->s_in.data(), n, hipMemcpyHostToDevice, c->stream));
+        size_t zlen = bound & ~(size_t)3;
+        HIPCHK(hipMemsetAsync(c->h_out, 0, zlen, c->stream));
+        const bool header = c->s_bitcnt < 0; // stream header still to be written
+        u64 bitpos = header ? 32 : (u64)c->s_bitcnt;
+        u32 scrc = c->s_stream_crc;
+        size_t used = compress_core(c, c->h_in, n, c->s_level, c->h_out, zlen, &bitpos, &scrc, header, final);
+        c->s_stream_crc = scrc;
+        if (final || used > 0) {
+            size_t nbytes = (size_t)((bitpos + 7) / 8);
+            std::vector<u8> tmp(nbytes);
+            if (nbytes) HIPCHK(hipMemcpy(tmp.data(), c->h_out, nbytes, hipMemcpyDeviceToHost));
+            if (!header && c->s_bitcnt > 0) tmp[0] |= (u8)c->s_bitbuf;
+            size_t full = final ? nbytes : (size_t)(bitpos / 8);
+            c->s_out.insert(c->s_out.end(), tmp.begin(), tmp.begin() + full);
+            if (!final) {
+                c->s_bitcnt = (int)(bitpos & 7);
+                c->s_bitbuf = c->s_bitcnt ? tmp[full] : 0;
+            } else {
+                c->s_bitcnt = 0;
+                c->s_bitbuf = 0;
+            }
+        }
+        c->s_in.erase(c->s_in.begin(), c->s_in.begin() + used);
+        return BZ2HIP_OK;
+    });
+}
+
+extern "C" int bz2hip_stream_write(bz2hip_ctx *c, const uint8_t *p, size_t n) {
+    if (!c) return BZ2HIP_E_PARAM;
+    if (!c->s_open || c->s_finished) return fail(c, BZ2HIP_E_STATE, "Write beyond end of stream");
+    if (n && !p) return fail(c, BZ2HIP_E_PARAM, "null pointer");
+    try {
+        c->s_in.insert(c->s_in.end(), p, p + n);
+    } catch (const std::bad_alloc &) {
+        return fail(c, BZ2HIP_E_NOMEM, "host allocation failed");
+    }
+    if (c->s_in.size() >= STREAM_CHUNK) return stream_flush(c, false);
+    return BZ2HIP_OK;
+}
+
+extern "C" int bz2hip_stream_finish(bz2hip_ctx *c) {
+    if (!c) return BZ2HIP_E_PARAM;
+    if (!c->s_open) return fail(c, BZ2HIP_E_STATE, "stream not open");
+    if (c->s_finished) return BZ2HIP_OK; // finish() is idempotent (S/BZip2OutputStream.swift:151)
+    int rc = stream_flush(c, true);
+    if (rc == BZ2HIP_OK) c->s_finished = true;
+    return rc;
+}
+
+extern "C" int bz2hip_stream_read(bz2hip_ctx *c, uint8_t *out, size_t cap, size_t *produced) {
+    if (!c || !produced) return BZ2HIP_E_PARAM;
+    size_t avail = c->s_out.size() - c->s_out_pos;
+    size_t k = std::min(avail, cap);
+    if (k) memcpy(out, c->s_out.data() + c->s_out_pos, k);
+    c->s_out_pos += k;
+    if (c->s_out_pos == c->s_out.size()) {
+        c->s_out.clear();
+        c->s_out_pos = 0;
+    }
+    *produced = k;
+    return BZ2HIP_OK;
+}
+
+extern "C" size_t bz2hip_stream_pending(const bz2hip_ctx *c) {
+    return c ? c->s_out.size() - c->s_out_pos : 0;
+}
+
+// ------------------------------------------------------------------ stage entry points
+static void upload_present(bz2hip_ctx *c, const uint8_t *present, u32 b0, int nb) {
+    std::vector<u32> w((size_t)nb * 8, 0);
+    for (int b = 0; b < nb; b++)
+        for (int v = 0; v < 256; v++)
+            if (present[((size_t)b0 + b) * 256 + v]) w[(size_t)b * 8 + (v >> 5)] |= 1u << (v & 31);
+    HIPCHK(hipMemcpy(c->batch.present, w.data(), w.size() * sizeof(u32), hipMemcpyHostToDevice));
+}
+
+static int level_for_maxn(u32 maxn) {
+    int level = (int)((maxn + 99999) / 100000);
+    if (level < 1) level = 1;
+    return level;
+}
+
+extern "C" int bz2hip_bwt(bz2hip_ctx *c, const uint8_t *blocks, const uint32_t *n, uint32_t count,
+                          uint32_t stride, uint8_t *bwt, uint32_t *orig, uint32_t *rounds) {
+    return guarded(c, [&]() -> int {
+        if (!blocks || !n || !bwt || !orig) return fail(c, BZ2HIP_E_PARAM, "null pointer");
+        u32 maxn = 0;
+        for (u32 b = 0; b < count; b++) maxn = std::max(maxn, n[b]);
+        if (maxn > 900000 || maxn > stride) return fail(c, BZ2HIP_E_PARAM, "block longer than 900000 or stride");
+        ensure_batch(c, level_for_maxn(maxn), (int)count);
+        Batch &B = c->batch;
+        for (u32 b0 = 0; b0 < count; b0 += (u32)B.NB) {
+            int nb = (int)std::min<u32>((u32)B.NB, count - b0);
+            HIPCHK(hipMemcpy2D(B.T, B.S, blocks + (size_t)b0 * stride, stride, maxn, nb, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(B.n, n + b0, nb * sizeof(u32), hipMemcpyHostToDevice));
+            run_bwt_n(c, nb, maxn);
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (maxn) HIPCHK(hipMemcpy2D(bwt + (size_t)b0 * stride, stride, B.bwt, B.S, maxn, nb, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(orig + b0, B.orig, nb * sizeof(u32), hipMemcpyDeviceToHost));
+            if (rounds) HIPCHK(hipMemcpy(rounds + b0, B.rounds, nb * sizeof(u32), hipMemcpyDeviceToHost));
+        }
+        if (c->profile) c->prof_collect();
+        return BZ2HIP_OK;
+    });
+}
+
+extern "C" int bz2hip_mtf_rle2(bz2hip_ctx *c, const uint8_t *bwt, const uint32_t *n, uint32_t count,
+                               uint32_t stride, const uint8_t *present, uint16_t *mtf,
+                               uint32_t *mtf_len, uint32_t *alpha, int32_t *freq) {
+    return guarded(c, [&]() -> int {
+        if (!bwt || !n || !present || !mtf || !mtf_len || !alpha || !freq)
+            return fail(c, BZ2HIP_E_PARAM, "null pointer");
+        u32 maxn = 0;
+        for (u32 b = 0; b < count; b++) maxn = std::max(maxn, n[b]);
+        if (maxn > 900000 || maxn > stride) return fail(c, BZ2HIP_E_PARAM, "block longer than 900000 or stride");
+        ensure_batch(c, level_for_maxn(maxn), (int)count);
+        Batch &B = c->batch;
+        const size_t S2 = B.S + 64;
+        for (u32 b0 = 0; b0 < count; b0 += (u32)B.NB) {
+            int nb = (int)std::min<u32>((u32)B.NB, count - b0);
+            if (maxn) HIPCHK(hipMemcpy2D(B.bwt, B.S, bwt + (size_t)b0 * stride, stride, maxn, nb, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(B.n, n + b0, nb * sizeof(u32), hipMemcpyHostToDevice));
+            upload_present(c, present, b0, nb);
+            run_mtf(c, nb, maxn);
+            HIPCHK(hipStreamSynchronize(c->stream));
+            HIPCHK(hipMemcpy2D(mtf + (size_t)b0 * (stride + 2), (size_t)(stride + 2) * 2, B.mtf, S2 * 2,
+                               (size_t)(maxn + 1) * 2, nb, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(mtf_len + b0, B.mtflen, nb * sizeof(u32), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(alpha + b0, B.alpha, nb * sizeof(u32), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy2D(freq + (size_t)b0 * 258, 258 * 4, B.freq, 264 * 4, 258 * 4, nb, hipMemcpyDeviceToHost));
+        }
+        if (c->profile) c->prof_collect();
+        return BZ2HIP_OK;
+    });
+}
+
+extern "C" int bz2hip_huffman(bz2hip_ctx *c, const uint16_t *mtf, const uint32_t *mtf_len,
+                              const uint32_t *alpha, const int32_t *freq, uint32_t count,
+                              uint32_t stride, uint32_t *n_tables, int32_t *lengths,
+                              uint8_t *selectors, uint32_t sel_stride, uint32_t *n_selectors) {
+    return guarded(c, [&]() -> int {
+        if (!mtf || !mtf_len || !alpha || !freq || !n_tables || !lengths || !selectors || !n_selectors)
+            return fail(c, BZ2HIP_E_PARAM, "null pointer");
+        u32 maxl = 0;
+        for (u32 b = 0; b < count; b++) maxl = std::max(maxl, mtf_len[b]);
+        if (maxl > 900001 || maxl > stride) return fail(c, BZ2HIP_E_PARAM, "mtf block too long");
+        ensure_batch(c, level_for_maxn(maxl > 0 ? maxl - 1 : 0), (int)count);
+        Batch &B = c->batch;
+        const size_t S2 = B.S + 64;
+        for (u32 b0 = 0; b0 < count; b0 += (u32)B.NB) {
+            int nb = (int)std::min<u32>((u32)B.NB, count - b0);
+            HIPCHK(hipMemcpy2D(B.mtf, S2 * 2, mtf + (size_t)b0 * stride, (size_t)stride * 2, (size_t)maxl * 2, nb,
+                               hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(B.mtflen, mtf_len + b0, nb * sizeof(u32), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(B.alpha, alpha + b0, nb * sizeof(u32), hipMemcpyHostToDevice));
+            HIPCHK(hipMemset(B.freq, 0, (size_t)nb * 264 * 4));
+            HIPCHK(hipMemcpy2D(B.freq, 264 * 4, freq + (size_t)b0 * 258, 258 * 4, 258 * 4, nb, hipMemcpyHostToDevice));
+            run_huffman(c, nb, maxl);
+            HIPCHK(hipStreamSynchronize(c->stream));
+            HIPCHK(hipMemcpy(n_tables + b0, B.ntables, nb * sizeof(u32), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(n_selectors + b0, B.nsel, nb * sizeof(u32), hipMemcpyDeviceToHost));
+            std::vector<u8> hl((size_t)nb * MAX_TABLES * 264);
+            HIPCHK(hipMemcpy(hl.data(), B.hlen, hl.size(), hipMemcpyDeviceToHost));
+            for (int b = 0; b < nb; b++)
+                for (int t = 0; t < MAX_TABLES; t++)
+                    for (int j = 0; j < 258; j++)
+                        lengths[(((size_t)b0 + b) * MAX_TABLES + t) * 258 + j] =
+                            hl[((size_t)b * MAX_TABLES + t) * 264 + j];
+            u32 w = std::min<u32>(sel_stride, SEL_STRIDE);
+            HIPCHK(hipMemcpy2D(selectors + (size_t)b0 * sel_stride, sel_stride, B.sel, SEL_STRIDE, w, nb,
+                               hipMemcpyDeviceToHost));
+        }
+        if (c->profile) c->prof_collect();
+        return BZ2HIP_OK;
+    });
+}
+
+extern "C" int bz2hip_block_compress(bz2hip_ctx *c, const uint8_t *rle_blocks, const uint32_t *n,
+                                     uint32_t count, uint32_t stride, const uint8_t *present,
+                                     const uint32_t *crc, uint8_t *bits, size_t bits_stride,
+                                     uint64_t *nbits) {
+    return guarded(c, [&]() -> int {
+        if (!rle_blocks || !n || !present || !crc || !bits || !nbits)
+            return fail(c, BZ2HIP_E_PARAM, "null pointer");
+        if (bits_stride & 3) return fail(c, BZ2HIP_E_PARAM, "bits_stride must be a multiple of 4");
+        u32 maxn = 0;
+        for (u32 b = 0; b < count; b++) {
+            if (n[b] == 0) return fail(c, BZ2HIP_E_PARAM, "empty block");
+            maxn = std::max(maxn, n[b]);
+        }
+        if (maxn > 900000 || maxn > stride) return fail(c, BZ2HIP_E_PARAM, "block longer than 900000 or stride");
+        ensure_batch(c, level_for_maxn(maxn), (int)count);
+        Batch &B = c->batch;
+        ensure_staging(c, 0, (size_t)B.NB * bits_stride);
+        for (u32 b0 = 0; b0 < count; b0 += (u32)B.NB) {
+            int nb = (int)std::min<u32>((u32)B.NB, count - b0);
+            HIPCHK(hipMemcpy2D(B.T, B.S, rle_blocks + (size_t)b0 * stride, stride, maxn, nb, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(B.n, n + b0, nb * sizeof(u32), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(B.crc, crc + b0, nb * sizeof(u32), hipMemcpyHostToDevice));
+            upload_present(c, present, b0, nb);
+            HIPCHK(hipMemsetAsync(c->h_out, 0, (size_t)nb * bits_stride, c->stream));
+            run_bwt_n(c, nb, maxn);
+            run_mtf(c, nb, maxn);
+            run_huffman(c, nb, maxn + 1);
+            std::vector<u64> hb;
+            run_pack(c, nb, maxn + 1, c->h_out, 0, true, bits_stride, 0, &hb);
+            HIPCHK(hipStreamSynchronize(c->stream));
+            HIPCHK(hipMemcpy(bits + (size_t)b0 * bits_stride, c->h_out, (size_t)nb * bits_stride, hipMemcpyDeviceToHost));
+            for (int b = 0; b < nb; b++) nbits[b0 + b] = hb[b];
+        }
+        if (c->profile) c->prof_collect();
+        return BZ2HIP_OK;
+    });
+}
+
+extern "C" int bz2hip_rle1_split(bz2hip_ctx *c, const uint8_t *in, size_t n, int level,
+                                 uint32_t max_blocks, uint32_t *n_blocks, uint64_t *starts,
+                                 uint8_t *rle, uint32_t *rle_len, uint8_t *present, uint32_t *crc) {
+    return guarded(c, [&]() -> int {
+        if (level < 1 || level > 9) return fail(c, BZ2HIP_E_PARAM, "Invalid BZip2 block size");
+        if (!n_blocks || !starts || (n && !in)) return fail(c, BZ2HIP_E_PARAM, "null pointer");
+        if (n > WMAX) return fail(c, BZ2HIP_E_PARAM, "input larger than one window (1 GiB)");
+        *n_blocks = 0;
+        if (n == 0) return BZ2HIP_OK;
+        const u32 bs = (u32)level * 100000u;
+        const size_t rstride = (size_t)bs + 8;
+        ensure_staging(c, n, 0);
+        HIPCHK(hipMemcpyAsync(c->h_in, in, n, hipMemcpyHostToDevice, c->stream));
+        ensure_batch(c, level, (int)std::min<size_t>(n / (bs - 4) + 1, 1u << 20));
+        ensure_window(c, n, level);
+        std::vector<u32> hs;
+        u32 cnt = run_split(c, c->h_in, (u32)n, level, c->w_rs, c->w_P, c->w_agg1, c->w_agg2,
+                            c->w_starts, c->w_maxblocks, hs);
+        if (cnt > max_blocks) return fail(c, BZ2HIP_E_CAP, "more blocks than max_blocks");
+        *n_blocks = cnt;
+        for (u32 b = 0; b < cnt; b++) starts[b] = hs[b];
+        if (!rle || !rle_len || !present || !crc) return BZ2HIP_OK;
+        Batch &B = c->batch;
+        for (u32 b0 = 0; b0 < cnt; b0 += (u32)B.NB) {
+            int nb = (int)std::min<u32>((u32)B.NB, cnt - b0);
+            u32 max_in = 0;
+            for (int b = 0; b < nb; b++) max_in = std::max(max_in, hs[b0 + b + 1] - hs[b0 + b]);
+            run_rle1_emit(c, c->h_in, c->w_rs, c->w_starts, b0, nb, max_in, c->w_eagg, c->w_ETPB);
+            HIPCHK(hipStreamSynchronize(c->stream));
+            HIPCHK(hipMemcpy2D(rle + (size_t)b0 * rstride, rstride, B.T, B.S, bs, nb, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(rle_len + b0, B.n, nb * sizeof(u32), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(crc + b0, B.crc, nb * sizeof(u32), hipMemcpyDeviceToHost));
+            std::vector<u32> pw((size_t)nb * 8);
+            HIPCHK(hipMemcpy(pw.data(), B.present, pw.size() * 4, hipMemcpyDeviceToHost));
+            for (int b = 0; b < nb; b++)
+                for (int v = 0; v < 256; v++)
+                    present[((size_t)b0 + b) * 256 + v] = (pw[(size_t)b * 8 + (v >> 5)] >> (v & 31)) & 1u;
+        }
+        if (c->profile) c->prof_collect();
+        return BZ2HIP_OK;
+    });
+}
+
+// ------------------------------------------------------------------ profiling
+static const char *k_prof_names[P_COUNT] = {
+    "rle1_scan", "rle1_split", "rle1_emit", "crc", "bwt_init", "radix_hist", "radix_scan",
+    "radix_scatter", "bwt_keys", "bwt_rerank", "bwt_emit", "mtf_state", "mtf_compose",
+    "mtf_replay", "rle2", "huf_seed", "huf_select", "huf_lengths", "huf_codes", "huf_header",
+    "pack", "frame"};
+
+extern "C" int bz2hip_profile_reset(bz2hip_ctx *c) {
+    if (!c) return BZ2HIP_E_PARAM;
+    for (int i = 0; i < P_COUNT; i++) {
+        c->prof_ms[i] = 0;
+        c->prof_launches[i] = 0;
+        c->prof_bytes[i] = 0;
+    }
+    return BZ2HIP_OK;
+}
+
+extern "C" int bz2hip_profile_get(bz2hip_ctx *c, int *count, const char **names, double *ms,
+                                  uint64_t *launches, double *alg_bytes) {
+    if (!c || !count) return BZ2HIP_E_PARAM;
+    *count = P_COUNT;
+    for (int i = 0; i < P_COUNT; i++) {
+        if (names) names[i] = k_prof_names[i];
+        if (ms) ms[i] = c->prof_ms[i];
+        if (launches) launches[i] = c->prof_launches[i];
+        if (alg_bytes) alg_bytes[i] = c->prof_bytes[i];
+    }
+    return BZ2HIP_OK;
+}
+
+extern "C" int bz2hip_last_stats(bz2hip_ctx *c, uint64_t *blocks, uint64_t *rounds_sum,
+                                 uint64_t *rle_bytes, uint64_t *periodic_blocks) {
+    if (!c) return BZ2HIP_E_PARAM;
+    if (blocks) *blocks = c->st_blocks;
+    if (rounds_sum) *rounds_sum = c->st_rounds;
+    if (rle_bytes) *rle_bytes = c->st_rle_bytes;
+    if (periodic_blocks) *periodic_blocks = c->st_periodic;
+    return BZ2HIP_OK;
+}

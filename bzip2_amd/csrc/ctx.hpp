@@ -1,0 +1,178 @@
+// ctx.hpp -- host-side context, workspace and launch helper of libbz2hip.
+#pragma once
+#include "common.hpp"
+#include "../../include/bz2hip.h"
+
+#include <string>
+#include <vector>
+#include <stdexcept>
+#include <cstdio>
+
+struct HipError : std::runtime_error {
+    int code;
+    HipError(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            char _buf[512];                                                                  \
+            snprintf(_buf, sizeof(_buf), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                     __FILE__, __LINE__);                                                    \
+            throw HipError(_e == hipErrorOutOfMemory ? BZ2HIP_E_NOMEM : BZ2HIP_E_HIP, _buf); \
+        }                                                                                    \
+    } while (0)
+
+// Device workspace for one batch of up to NB blocks laid out at stride S elements.
+struct Batch {
+    int NB = 0;      // capacity (blocks)
+    u32 S = 0;       // elements per block slot (multiple of RTILE), >= block_size + 8
+    u32 TPB = 0;     // radix tiles per block slot = S / RTILE
+    // block inputs
+    u8 *T = nullptr;        // [NB][S]
+    u32 *n = nullptr;       // [NB]
+    u32 *present = nullptr; // [NB][8] bitmap words (bit v of word v>>5)
+    u32 *crc = nullptr;     // [NB]
+    // BWT
+    u64 *keyA = nullptr, *keyB = nullptr;
+    u32 *valA = nullptr, *valB = nullptr;
+    u32 *rank = nullptr, *grp = nullptr, *sa = nullptr;
+    u32 *tilehist = nullptr;  // [NB][TPB][256]
+    u32 *digitbase = nullptr; // [NB][256]
+    u32 *tileagg = nullptr;   // [NB][TPB]
+    u32 *nheads = nullptr;    // [NB]
+    u32 *active = nullptr;    // [NB]
+    u32 *rounds = nullptr;    // [NB]
+    u32 *ctl = nullptr;       // [4] device control words (any_active, ...)
+    u8 *bwt = nullptr;        // [NB][S]
+    u32 *orig = nullptr;      // [NB]
+    u32 *periodic = nullptr;  // [NB] period count k (1 = aperiodic)
+    // MTF / RLE2
+    u8 *mtfrec = nullptr;     // [NB][chunks][256] recency lists, then entry states
+    u32 *mtfcnt = nullptr;    // [NB][chunks]
+    u8 *mtfpos = nullptr;     // [NB][S]
+    u32 *r2agg = nullptr;     // [NB][TPB][4] tile summaries (lz, tz, inner, allzero) -> offsets
+    u16 *mtf = nullptr;       // [NB][S+?]  (slot size S2 = S + 64 halfwords)
+    u32 *mtflen = nullptr;    // [NB]
+    u32 *alpha = nullptr;     // [NB]
+    u32 *freq = nullptr;      // [NB][258 -> 264]
+    // Huffman
+    u32 *ntables = nullptr;   // [NB]
+    u8 *hlen = nullptr;       // [NB][6][264] code lengths
+    u32 *hpart = nullptr;     // [NB][HS_PART_MAX][6][264] partial table frequencies
+    u32 *hfreq = nullptr;     // [NB][6][264] final-pass table frequencies
+    u32 *hcode = nullptr;     // [NB][6][264] (len<<24)|code
+    u8 *sel = nullptr;        // [NB][SEL_STRIDE]
+    u8 *selpos = nullptr;     // [NB][SEL_STRIDE] MTF'd selectors
+    u32 *nsel = nullptr;      // [NB]
+    u64 *tblbits = nullptr;   // [NB][6][2]: serialised table bits, data bits per table
+    u64 *hdrbits = nullptr;   // [NB][4]: header bits, selector bits, table bits, data bits
+    u64 *bitoff = nullptr;    // [2*(NB+1)] absolute bit offset of each block, then bit lengths
+    u32 *pkagg = nullptr;     // [NB][S/PK_TILE] tile bit sums -> offsets
+    size_t bytes = 0;
+};
+
+struct ProfRec {
+    int cls;
+    hipEvent_t e0, e1;
+};
+
+struct bz2hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bz2hip_opts opts{};
+    std::string err;
+    Batch batch;
+    std::vector<void *> allocs;
+    // window scratch for K1 (split / RLE1 / CRC)
+    u32 *w_rs = nullptr, *w_P = nullptr, *w_agg1 = nullptr, *w_agg2 = nullptr;
+    u32 *w_starts = nullptr, *w_eagg = nullptr;
+    size_t w_cap = 0;        // window capacity in input bytes
+    u32 w_maxblocks = 0;
+    u32 w_ETPB = 0;          // emit tiles per block slot
+    int w_eagg_nb = 0;
+    // staging buffers for the host-pointer entry points
+    u8 *h_in = nullptr;  size_t h_in_cap = 0;
+    u8 *h_out = nullptr; size_t h_out_cap = 0;
+    // profiling
+    bool profile = false;
+    std::vector<ProfRec> prof_pending;
+    std::vector<hipEvent_t> ev_pool;
+    double prof_ms[P_COUNT] = {0};
+    u64 prof_launches[P_COUNT] = {0};
+    double prof_bytes[P_COUNT] = {0};
+    // stats of the last call
+    u64 st_blocks = 0, st_rounds = 0, st_rle_bytes = 0, st_periodic = 0;
+    // streaming state
+    int s_level = 0;
+    bool s_open = false, s_finished = false;
+    std::vector<u8> s_in;      // buffered, not yet compressed input
+    std::vector<u8> s_out;     // compressed bytes not yet drained
+    size_t s_out_pos = 0;
+    u32 s_stream_crc = 0;
+    u32 s_bitbuf = 0;          // pending partial byte (left aligned in low 8 bits)
+    int s_bitcnt = 0;
+
+    hipEvent_t get_event() {
+        if (!ev_pool.empty()) {
+            hipEvent_t e = ev_pool.back();
+            ev_pool.pop_back();
+            return e;
+        }
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        return e;
+    }
+    void prof_collect() {
+        for (auto &r : prof_pending) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+                prof_ms[r.cls] += ms;
+                prof_launches[r.cls] += 1;
+            }
+            ev_pool.push_back(r.e0);
+            ev_pool.push_back(r.e1);
+        }
+        prof_pending.clear();
+    }
+};
+
+// Launch helper: records a HIP event pair around the launch when profiling is on.
+struct ProfScope {
+    bz2hip_ctx *c;
+    int cls;
+    hipEvent_t e0 = nullptr;
+    ProfScope(bz2hip_ctx *ctx, int k, double alg_bytes = 0) : c(ctx), cls(k) {
+        if (c->profile) {
+            e0 = c->get_event();
+            HIPCHK(hipEventRecord(e0, c->stream));
+            c->prof_bytes[cls] += alg_bytes;
+        }
+    }
+    ~ProfScope() {
+        if (c->profile && e0) {
+            hipEvent_t e1 = c->get_event();
+            hipEventRecord(e1, c->stream);
+            c->prof_pending.push_back({cls, e0, e1});
+        }
+    }
+};
+
+#define KCHECK() HIPCHK(hipGetLastError())
+
+// stage drivers (each in its own .hip file)
+void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn);                       // k2_bwt.hip
+void run_mtf(bz2hip_ctx *c, int nb, u32 maxn);                         // k3_mtf.hip
+void run_huffman(bz2hip_ctx *c, int nb, u32 maxmtf);                   // k4_huffman.hip
+// writes blocks at absolute bit offsets into d_out (zeroed); first_bit = bit offset of block 0
+void run_pack(bz2hip_ctx *c, int nb, u32 maxmtf, u8 *d_out, u64 first_bit, bool per_block,
+              size_t bits_stride, size_t out_cap_bytes, std::vector<u64> *h_nbits); // k4_huffman.hip
+void run_frame(bz2hip_ctx *c, int nb, u8 *d_out, int level, bool header, bool trailer, u32 crc_in,
+               u64 *end_bit, u32 *crc_out);                            // k4_huffman.hip
+// K1 (k1_rle1.hip)
+void k1_init_tables(bz2hip_ctx *c);
+u32 run_split(bz2hip_ctx *c, const u8 *d_in, u32 n, int level, u32 *d_rs, u32 *d_P, u32 *d_agg1,
+              u32 *d_agg2, u32 *d_starts, u32 max_blocks, std::vector<u32> &h_starts);
+void run_rle1_emit(bz2hip_ctx *c, const u8 *d_in, const u32 *d_rs, const u32 *d_starts, u32 b0,
+                   int nb, u32 max_in_len, u32 *d_eagg, u32 ETPB);

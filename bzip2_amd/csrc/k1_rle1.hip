@@ -1,0 +1,485 @@
+// k1_rle1.hip -- block splitting, RLE1 and block CRC on the device.
+//
+// Replaces BZip2BlockCompressor.write / writeRun (S/BZip2BlockCompressor.swift:151-252) and
+// BZip2CRC32 (S/BZip2CRC32.swift:32-105) for a window of input bytes resident in HBM.
+//
+// Acceptance rule (:198-227): a byte is refused when the bytes *flushed* so far exceed
+// blockSize-6.  Runs are flushed when a different byte is accepted, or at 255 bytes.  With
+//   head(i)  = i == 0 || in[i] != in[i-1]
+//   rs(i)    = start of the maximal run containing i            (max-scan of head positions)
+//   c(i)     = 5 if (i - rs(i) + 1) % 255 == 0                  (a full 255-chunk flushed)
+//            + rem((i - rs(i-1)) % 255) if head(i), i > 0       (remainder of the run ending at i-1)
+//   P(i)     = sum_{j<i} c(j)                                   (bytes flushed when i is offered,
+//                                                                for a block that began at 0)
+// a block that starts at s (possibly inside a run that ends at re0) has flushed
+//   5*floor((i-s)/255)                         for i <= re0
+//   enc(re0-s) + P(i) - P(re0+1)               for i >  re0
+// so the first refused position is found by a monotone search on P.  Blocks form a serial
+// chain (each start is the previous end); one wavefront walks it with 64-ary searches.
+#include "ctx.hpp"
+
+#define K1_TILE 4096
+#define K1_NONE 0u
+
+__device__ __forceinline__ u32 enc_rem(u32 r) { return r < 4 ? r : 5u; }
+
+// phase 1: last head position + 1 per tile
+__global__ __launch_bounds__(256) void k1_heads_p1(const u8 *__restrict__ in, u32 n,
+                                                   u32 *__restrict__ agg) {
+    const u32 base = blockIdx.x * K1_TILE;
+    __shared__ u32 sm[8];
+    u32 last = 0;
+#pragma unroll 4
+    for (int k = 0; k < 16; k++) {
+        u32 i = base + k * 256 + threadIdx.x;
+        if (i < n) {
+            bool head = (i == 0) || (in[i] != in[i - 1]);
+            if (head) last = i + 1;
+        }
+    }
+    u32 t = block_reduce_max<256>(last, sm);
+    if (threadIdx.x == 0) agg[blockIdx.x] = t;
+}
+
+// exclusive scans over a flat array of tile aggregates (single workgroup of 1024)
+template <bool MAXOP>
+__global__ __launch_bounds__(1024) void k1_scan_tiles(u32 *__restrict__ agg, u32 count,
+                                                      u32 *__restrict__ total_out) {
+    __shared__ u32 sm[20];
+    u32 carry = 0;
+    for (u32 t0 = 0; t0 < count; t0 += 1024) {
+        u32 t = t0 + threadIdx.x;
+        u32 v = (t < count) ? agg[t] : 0;
+        u32 tot, ex;
+        if (MAXOP) {
+            u32 inc = block_incl_scan_max<1024>(v, sm, &tot);
+            u32 prev = __shfl_up(inc, 1, 64);
+            if (lane_id() == 0) {
+                ex = 0;
+                for (int q = 0; q < wave_id(); q++) ex = max(ex, sm[q]);
+            } else {
+                ex = prev;
+            }
+            ex = max(ex, carry);
+            carry = max(carry, tot);
+        } else {
+            ex = carry + block_excl_scan_add<1024>(v, sm, &tot);
+            carry += tot;
+        }
+        if (t < count) agg[t] = ex;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = carry;
+}
+
+// per-row helper: run start of every element of the tile, wave-row layout
+// phase 3: rs[i] and tile sums of c(i)
+template <bool WRITE_P>
+__global__ __launch_bounds__(256) void k1_runs(const u8 *__restrict__ in, u32 n,
+                                               const u32 *__restrict__ agg_head,
+                                               u32 *__restrict__ rs, u32 *__restrict__ agg_c,
+                                               u32 *__restrict__ P) {
+    const u32 base = blockIdx.x * K1_TILE;
+    const int w = wave_id(), lane = lane_id();
+    __shared__ u32 wlast[4];
+    __shared__ u32 wsum[4];
+    u64 hm[16];
+    u32 last = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        u32 i = base + w * 1024 + k * 64 + lane;
+        bool head = false;
+        if (i < n) head = (i == 0) || (in[i] != in[i - 1]);
+        u64 m = __ballot(head);
+        hm[k] = m;
+        if (m) last = base + w * 1024 + k * 64 + (63 - __clzll((unsigned long long)m)) + 1;
+    }
+    if (lane == 0) wlast[w] = last;
+    __syncthreads();
+    u32 carry = agg_head[blockIdx.x]; // last head (+1) before this tile
+    for (int q = 0; q < w; q++) carry = max(carry, wlast[q]);
+    u32 cv[16];
+    u32 wtot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        u32 rowbase = base + w * 1024 + k * 64;
+        u32 i = rowbase + lane;
+        u64 m = hm[k];
+        bool head = (m >> lane) & 1ull;
+        // last head strictly before i (+1)
+        u64 below = m & ((1ull << lane) - 1ull);
+        u32 prevp1 = below ? (rowbase + (63 - __clzll((unsigned long long)below)) + 1) : carry;
+        u32 c = 0;
+        if (i < n) {
+            u32 rsi = head ? i : (prevp1 - 1);
+            if (!WRITE_P) rs[i] = rsi;
+            if ((i - rsi + 1) % 255u == 0) c = 5;
+            if (head && i > 0) c += enc_rem((i - (prevp1 - 1)) % 255u);
+        }
+        cv[k] = c;
+        wtot += c;
+        if (m) carry = rowbase + (63 - __clzll((unsigned long long)m)) + 1;
+    }
+    wtot = wave_reduce_add(wtot);
+    if (!WRITE_P) {
+        if (lane == 0) wsum[w] = wtot;
+        __syncthreads();
+        if (threadIdx.x == 0) agg_c[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    } else {
+        if (lane == 0) wsum[w] = wtot;
+        __syncthreads();
+        u32 run = agg_c[blockIdx.x];
+        for (int q = 0; q < w; q++) run += wsum[q];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            u32 i = base + w * 1024 + k * 64 + lane;
+            u32 inc = wave_incl_scan_add(cv[k]);
+            if (i < n) P[i] = run + inc - cv[k];
+            run += __shfl(inc, 63, 64);
+        }
+    }
+}
+
+__global__ void k1_sentinels(u32 *rs, u32 *P, u32 n, const u32 *total) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        rs[n] = n;
+        P[n] = *total;
+    }
+}
+
+// first i in (lo, hi] with arr[i] > thr (arr non-decreasing); returns hi+1 if none.  One wave.
+__device__ u32 wave_search_gt(const u32 *__restrict__ arr, u32 lo, u32 hi, u32 thr) {
+    const int lane = lane_id();
+    if (lo >= hi) return hi + 1;
+    // invariant: answer in (lo, hi] or none; first check arr[hi]
+    u32 top = arr[hi];
+    if (!(top > thr)) return hi + 1;
+    while (hi - lo > 1) {
+        u32 width = hi - lo;
+        u32 step = (width + 63) / 64;
+        u32 idx = lo + (u32)(lane + 1) * step;
+        if (idx > hi) idx = hi;
+        bool pred = arr[idx] > thr;
+        u64 m = __ballot(pred);
+        int fl = __ffsll((unsigned long long)m) - 1; // exists since arr[hi] > thr
+        u32 nhi = lo + (u32)(fl + 1) * step;
+        if (nhi > hi) nhi = hi;
+        u32 nlo = lo + (u32)fl * step;
+        lo = nlo;
+        hi = nhi;
+    }
+    return hi;
+}
+
+// serial chain over blocks; one wave.  starts[k] for k <= count (starts[count] = end of last).
+__global__ __launch_bounds__(64) void k1_split(const u32 *__restrict__ rs,
+                                               const u32 *__restrict__ P, u32 n, u32 block_size,
+                                               u32 max_blocks, u32 *__restrict__ starts,
+                                               u32 *__restrict__ count_out) {
+    const u32 limit = block_size - 6;
+    u32 s = 0, cnt = 0;
+    while (s < n && cnt < max_blocks) {
+        if (lane_id() == 0) starts[cnt] = s;
+        // end of the maximal run containing s
+        u32 re0 = wave_search_gt(rs, s, n, s);
+        if (re0 > n) re0 = n;
+        u32 e;
+        u32 cand = s + 255u * (limit / 5u + 1u);
+        if (cand <= re0 && cand > s) {
+            e = cand;
+        } else if (re0 >= n) {
+            e = n;
+        } else {
+            u32 L0 = re0 - s;
+            u32 enc0 = 5u * (L0 / 255u) + enc_rem(L0 % 255u);
+            u32 hi = n;
+            // a block never swallows more than ~51x its size of input
+            u64 cap = (u64)s + (u64)block_size * 52ull + 1024ull;
+            if (cap < (u64)hi) hi = (u32)cap;
+            if (enc0 > limit) {
+                e = re0 + 1; // the first run alone overfills: refused right after the next head
+            } else {
+                u32 thr = limit - enc0 + P[re0 + 1];
+                e = wave_search_gt(P, re0, hi, thr);
+                if (e > hi) e = (hi == n) ? n : hi; // not expected when hi < n
+            }
+        }
+        cnt++;
+        s = e;
+    }
+    if (lane_id() == 0) {
+        starts[cnt] = s;
+        *count_out = cnt;
+    }
+}
+
+// ---------------------------------------------------------------- per-block RLE1 emit
+// element j of block b = input position starts[b0+b] + j.  3-phase scan of emitted bytes.
+__device__ __forceinline__ u32 emit_count(const u8 *__restrict__ in, const u32 *__restrict__ rs,
+                                          u32 s, u32 e, u32 i, u32 *count_byte, bool *has_count) {
+    u32 r0 = rs[i];
+    if (r0 < s) r0 = s;
+    u32 k = (i - r0) % 255u;
+    bool chunk_end = (k == 254u) || (i + 1 == e) || (in[i + 1] != in[i]);
+    bool hc = chunk_end && k >= 3u;
+    *has_count = hc;
+    *count_byte = k - 3u;
+    return (k < 4u ? 1u : 0u) + (hc ? 1u : 0u);
+}
+
+__global__ __launch_bounds__(256) void k1_emit_p1(const u8 *__restrict__ in,
+                                                  const u32 *__restrict__ rs,
+                                                  const u32 *__restrict__ starts,
+                                                  u32 *__restrict__ eagg, u32 ETPB) {
+    const u32 b = blockIdx.y;
+    const u32 s = starts[b], e = starts[b + 1];
+    const u32 base = s + blockIdx.x * K1_TILE;
+    if (base >= e) return;
+    __shared__ u32 sm[8];
+    u32 tot = 0;
+#pragma unroll 4
+    for (int k = 0; k < 16; k++) {
+        u32 i = base + k * 256 + threadIdx.x;
+        if (i < e) {
+            u32 cb;
+            bool hc;
+            tot += emit_count(in, rs, s, e, i, &cb, &hc);
+        }
+    }
+    u32 t = block_reduce_add<256>(tot, sm);
+    if (threadIdx.x == 0) eagg[(size_t)b * ETPB + blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(256) void k1_emit_p2(const u32 *__restrict__ starts,
+                                                  u32 *__restrict__ eagg, u32 *__restrict__ nOut,
+                                                  u32 *__restrict__ present, u32 ETPB) {
+    const u32 b = blockIdx.x;
+    const u32 len = starts[b + 1] - starts[b];
+    const u32 tiles = (len + K1_TILE - 1) / K1_TILE;
+    __shared__ u32 sm[8];
+    u32 carry = 0;
+    for (u32 t0 = 0; t0 < tiles; t0 += 256) {
+        u32 t = t0 + threadIdx.x;
+        u32 v = (t < tiles) ? eagg[(size_t)b * ETPB + t] : 0;
+        u32 tot;
+        u32 ex = block_excl_scan_add<256>(v, sm, &tot);
+        if (t < tiles) eagg[(size_t)b * ETPB + t] = carry + ex;
+        carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) nOut[b] = carry;
+    if (threadIdx.x < 8) present[b * 8 + threadIdx.x] = 0;
+}
+
+__global__ __launch_bounds__(256) void k1_emit_p3(const u8 *__restrict__ in,
+                                                  const u32 *__restrict__ rs,
+                                                  const u32 *__restrict__ starts,
+                                                  const u32 *__restrict__ eagg, u8 *__restrict__ T,
+                                                  u32 *__restrict__ present, u32 S, u32 ETPB) {
+    const u32 b = blockIdx.y;
+    const u32 s = starts[b], e = starts[b + 1];
+    const u32 base = s + blockIdx.x * K1_TILE;
+    if (base >= e) return;
+    const int w = wave_id(), lane = lane_id();
+    __shared__ u32 wsum[4];
+    __shared__ u32 pres[8];
+    if (threadIdx.x < 8) pres[threadIdx.x] = 0;
+    u32 ec[16], cbv[16];
+    u32 wtot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        u32 i = base + w * 1024 + k * 64 + lane;
+        u32 c = 0, cb = 0;
+        bool hc = false;
+        if (i < e) c = emit_count(in, rs, s, e, i, &cb, &hc);
+        ec[k] = c;
+        cbv[k] = hc ? cb : 0xffffffffu;
+        wtot += c;
+    }
+    wtot = wave_reduce_add(wtot);
+    if (lane == 0) wsum[w] = wtot;
+    __syncthreads();
+    u32 run = eagg[(size_t)b * ETPB + blockIdx.x];
+    for (int q = 0; q < w; q++) run += wsum[q];
+    u8 *out = T + (size_t)b * S;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        u32 i = base + w * 1024 + k * 64 + lane;
+        u32 c = ec[k];
+        u32 inc = wave_incl_scan_add(c);
+        u32 o = run + inc - c;
+        run += __shfl(inc, 63, 64);
+        if (c) {
+            u8 v = in[i];
+            bool hc = cbv[k] != 0xffffffffu;
+            if (c == 2 || !hc) { // the data byte itself is emitted
+                out[o++] = v;
+                atomicOr(&pres[v >> 5], 1u << (v & 31));
+            }
+            if (hc) {
+                u32 cb = cbv[k];
+                out[o] = (u8)cb;
+                atomicOr(&pres[cb >> 5], 1u << (cb & 31));
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 8 && pres[threadIdx.x]) atomicOr(&present[b * 8 + threadIdx.x], pres[threadIdx.x]);
+}
+
+// ---------------------------------------------------------------- CRC
+__constant__ u32 c_crc_table[256];
+__constant__ u32 c_xpow16[257]; // x^(128*m) mod P, m = 0..256
+__constant__ u32 c_xpow1[16];   // x^(8*r) mod P, r = 0..15
+
+__device__ __forceinline__ u32 gfmul(u32 a, u32 b) {
+    u32 r = 0;
+#pragma unroll 8
+    for (int i = 31; i >= 0; i--) {
+        r = (r << 1) ^ ((r & 0x80000000u) ? 0x04c11db7u : 0u);
+        if ((b >> i) & 1u) r ^= a;
+    }
+    return r;
+}
+
+// raw CRC (register from 0) of each 4096-byte tile of the block's input
+__global__ __launch_bounds__(256) void k1_crc_p1(const u8 *__restrict__ in,
+                                                 const u32 *__restrict__ starts,
+                                                 u32 *__restrict__ cagg, u32 ETPB) {
+    const u32 b = blockIdx.y;
+    const u32 s = starts[b], e = starts[b + 1];
+    const u32 base = s + blockIdx.x * K1_TILE;
+    if (base >= e) return;
+    __shared__ u32 tab[256];
+    __shared__ u32 sm[8];
+    tab[threadIdx.x] = c_crc_table[threadIdx.x];
+    __syncthreads();
+    const u32 tlen = min((u32)K1_TILE, e - base);
+    const u32 p0 = threadIdx.x * 16;
+    u32 reg = 0;
+    if (p0 < tlen) {
+        u32 cnt = min(16u, tlen - p0);
+        for (u32 q = 0; q < cnt; q++) reg = (reg << 8) ^ tab[((reg >> 24) ^ in[base + p0 + q]) & 0xff];
+        u32 after = tlen - (p0 + cnt); // bytes after this piece inside the tile
+        u32 mult = gfmul(c_xpow16[after >> 4], c_xpow1[after & 15]);
+        reg = gfmul(reg, mult);
+    }
+    // xor-reduce
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) reg ^= __shfl_xor(reg, d, 64);
+    if (lane_id() == 0) sm[wave_id()] = reg;
+    __syncthreads();
+    if (threadIdx.x == 0) cagg[(size_t)b * ETPB + blockIdx.x] = sm[0] ^ sm[1] ^ sm[2] ^ sm[3];
+}
+
+__global__ void k1_crc_p2(const u32 *__restrict__ starts, const u32 *__restrict__ cagg,
+                          u32 *__restrict__ crc, u32 nb, u32 ETPB) {
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const u32 len = starts[b + 1] - starts[b];
+    const u32 tiles = (len + K1_TILE - 1) / K1_TILE;
+    const u32 xfull = c_xpow16[256]; // x^(8*4096)
+    u32 acc = 0xffffffffu;
+    for (u32 t = 0; t < tiles; t++) {
+        u32 tlen = min((u32)K1_TILE, len - t * K1_TILE);
+        u32 mult = (tlen == K1_TILE) ? xfull : gfmul(c_xpow16[tlen >> 4], c_xpow1[tlen & 15]);
+        acc = gfmul(acc, mult) ^ cagg[(size_t)b * ETPB + t];
+    }
+    crc[b] = ~acc;
+}
+
+// ---------------------------------------------------------------- drivers
+static bool g_crc_tables_ready[64] = {false};
+
+static u32 h_gfmul(u32 a, u32 b) {
+    u32 r = 0;
+    for (int i = 31; i >= 0; i--) {
+        r = (r << 1) ^ ((r & 0x80000000u) ? 0x04c11db7u : 0u);
+        if ((b >> i) & 1u) r ^= a;
+    }
+    return r;
+}
+
+void k1_init_tables(bz2hip_ctx *c) {
+    if (c->device >= 0 && c->device < 64 && g_crc_tables_ready[c->device]) return;
+    u32 tab[256], xp16[257], xp1[16];
+    for (u32 i = 0; i < 256; i++) {
+        u32 v = i << 24;
+        for (int k = 0; k < 8; k++) v = (v & 0x80000000u) ? (v << 1) ^ 0x04c11db7u : (v << 1);
+        tab[i] = v;
+    }
+    // x^8 mod P: polynomial "1" is register value 1; multiply by x eight times
+    u32 x8 = 1;
+    for (int k = 0; k < 8; k++) x8 = (x8 << 1) ^ ((x8 & 0x80000000u) ? 0x04c11db7u : 0u);
+    xp1[0] = 1;
+    for (int r = 1; r < 16; r++) xp1[r] = h_gfmul(xp1[r - 1], x8);
+    u32 x128 = h_gfmul(xp1[15], x8);
+    xp16[0] = 1;
+    for (int m = 1; m <= 256; m++) xp16[m] = h_gfmul(xp16[m - 1], x128);
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_crc_table), tab, sizeof(tab)));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_xpow16), xp16, sizeof(xp16)));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_xpow1), xp1, sizeof(xp1)));
+    if (c->device >= 0 && c->device < 64) g_crc_tables_ready[c->device] = true;
+}
+
+// Scan a window of input: fills rs[0..n], P[0..n] and the block starts (device array).
+// Returns the number of blocks found (<= max_blocks); h_starts receives count+1 offsets.
+u32 run_split(bz2hip_ctx *c, const u8 *d_in, u32 n, int level, u32 *d_rs, u32 *d_P, u32 *d_agg1,
+              u32 *d_agg2, u32 *d_starts, u32 max_blocks, std::vector<u32> &h_starts) {
+    Batch &B = c->batch;
+    const u32 tiles = (n + K1_TILE - 1) / K1_TILE;
+    {
+        ProfScope ps(c, P_RLE1_SCAN, 0);
+        k1_heads_p1<<<tiles, 256, 0, c->stream>>>(d_in, n, d_agg1);
+        KCHECK();
+        k1_scan_tiles<true><<<1, 1024, 0, c->stream>>>(d_agg1, tiles, nullptr);
+        KCHECK();
+        k1_runs<false><<<tiles, 256, 0, c->stream>>>(d_in, n, d_agg1, d_rs, d_agg2, nullptr);
+        KCHECK();
+        k1_scan_tiles<false><<<1, 1024, 0, c->stream>>>(d_agg2, tiles, B.ctl + 8);
+        KCHECK();
+        k1_runs<true><<<tiles, 256, 0, c->stream>>>(d_in, n, d_agg1, nullptr, d_agg2, d_P);
+        KCHECK();
+        k1_sentinels<<<1, 64, 0, c->stream>>>(d_rs, d_P, n, B.ctl + 8);
+        KCHECK();
+    }
+    {
+        ProfScope ps(c, P_RLE1_SPLIT, 0);
+        k1_split<<<1, 64, 0, c->stream>>>(d_rs, d_P, n, (u32)level * 100000u, max_blocks, d_starts,
+                                          B.ctl + 9);
+        KCHECK();
+    }
+    u32 cnt = 0;
+    HIPCHK(hipMemcpyAsync(&cnt, B.ctl + 9, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    h_starts.resize(cnt + 1);
+    HIPCHK(hipMemcpyAsync(h_starts.data(), d_starts, sizeof(u32) * (cnt + 1), hipMemcpyDeviceToHost,
+                          c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return cnt;
+}
+
+// RLE1-encode blocks [b0, b0+nb) of the window into the batch; CRC per block.
+void run_rle1_emit(bz2hip_ctx *c, const u8 *d_in, const u32 *d_rs, const u32 *d_starts, u32 b0,
+                   int nb, u32 max_in_len, u32 *d_eagg, u32 ETPB) {
+    Batch &B = c->batch;
+    const u32 tiles = (max_in_len + K1_TILE - 1) / K1_TILE;
+    dim3 grid(tiles, nb);
+    {
+        ProfScope ps(c, P_RLE1_EMIT, 0);
+        k1_emit_p1<<<grid, 256, 0, c->stream>>>(d_in, d_rs, d_starts + b0, d_eagg, ETPB);
+        KCHECK();
+        k1_emit_p2<<<nb, 256, 0, c->stream>>>(d_starts + b0, d_eagg, B.n, B.present, ETPB);
+        KCHECK();
+        k1_emit_p3<<<grid, 256, 0, c->stream>>>(d_in, d_rs, d_starts + b0, d_eagg, B.T, B.present,
+                                                B.S, ETPB);
+        KCHECK();
+    }
+    {
+        ProfScope ps(c, P_CRC, 0);
+        k1_crc_p1<<<grid, 256, 0, c->stream>>>(d_in, d_starts + b0, d_eagg, ETPB);
+        KCHECK();
+        k1_crc_p2<<<(nb + 63) / 64, 64, 0, c->stream>>>(d_starts + b0, d_eagg, B.crc, nb, ETPB);
+        KCHECK();
+    }
+}

@@ -1,0 +1,421 @@
+// k3_mtf.hip -- Move-To-Front + RLE2 (RUNA/RUNB) stage, batched over blocks.
+//
+// Replaces BZip2MTFAndRLE2StageEncoder.encode() (BZip2MTFAndRLE2StageEncoder.java:50-134,
+// S/BZip2MTFAndRLE2StageEncoder.swift:43-127) and MoveToFront.valueToFront
+// (S/BZip2MoveToFront.swift:66-82).
+//
+// MTF is a sequential recurrence over the BWT string.  It is cut into chunks of MTF_CHUNK
+// symbols, one wavefront per chunk, the 256-entry list held 4 entries per lane:
+//   mtf_state   : run the chunk from the identity list -> recency list (distinct symbols by
+//                 last occurrence, latest first) and its length d
+//   mtf_compose : one wave per block walks the chunks: entry_state(c+1) =
+//                 recency(c) ++ (entry_state(c) minus recency(c))
+//   mtf_replay  : re-run every chunk from its entry state -> MTF position per BWT byte
+// RLE2: zero runs (joined across tiles) become bijective base-2 RUNA/RUNB digits, positions
+// p > 0 become symbol p+1, EOB is appended; output slots by a tile scan.
+#include "ctx.hpp"
+
+#define MTF_WG_CHUNKS 4
+
+__device__ __forceinline__ u32 identity_list() {
+    u32 l = lane_id() * 4;
+    return l | ((l + 1) << 8) | ((l + 2) << 16) | ((l + 3) << 24);
+}
+
+// One MTF step on the wave-distributed list.  s is wave-uniform.  Returns the position.
+__device__ __forceinline__ u32 mtf_step(u32 &L, u32 s) {
+    const int lane = lane_id();
+    u32 x = L ^ (s * 0x01010101u);
+    u32 z = (x - 0x01010101u) & ~x & 0x80808080u; // lowest flagged byte is an exact zero byte
+    u64 m = __ballot(z != 0);
+    int src = __ffsll((unsigned long long)m) - 1;
+    u32 zz = __builtin_amdgcn_readlane(z, src);
+    u32 k = (u32)(__ffs(zz) - 1) >> 3;
+    u32 pos = (u32)src * 4u + k;
+    if (pos != 0) {
+        u32 up = __shfl_up(L, 1, 64);
+        u32 carry = (lane == 0) ? s : (up >> 24);
+        u32 shifted = (L << 8) | carry;
+        if (lane < src) {
+            L = shifted;
+        } else if (lane == src) {
+            u32 keep = (k == 3) ? 0u : (0xffffffffu << (8u * (k + 1u)));
+            L = (shifted & ~keep) | (L & keep);
+        }
+    }
+    return pos;
+}
+
+// byte -> dense symbol map from the present bitmap (java:60-65); smap[256] in LDS
+__device__ __forceinline__ void build_symbol_map(const u32 *__restrict__ presentWords, u8 *smap) {
+    if (threadIdx.x < 256) {
+        u32 v = threadIdx.x;
+        u32 cnt = 0;
+        for (u32 wi = 0; wi < (v >> 5); wi++) cnt += __popc(presentWords[wi]);
+        cnt += __popc(presentWords[v >> 5] & ((1u << (v & 31)) - 1u));
+        smap[v] = (u8)cnt;
+    }
+}
+
+template <bool REPLAY>
+__global__ __launch_bounds__(256) void k3_mtf_chunks(const u8 *__restrict__ bwt,
+                                                     const u32 *__restrict__ nArr,
+                                                     const u32 *__restrict__ present,
+                                                     u8 *__restrict__ mtfrec,
+                                                     u32 *__restrict__ mtfcnt,
+                                                     u8 *__restrict__ mtfpos, u32 S, u32 CPB) {
+    const u32 b = blockIdx.y;
+    const u32 n = nArr[b];
+    __shared__ u8 smap[256];
+    build_symbol_map(present + b * 8, smap);
+    __syncthreads();
+    const u32 c = blockIdx.x * MTF_WG_CHUNKS + wave_id();
+    const u32 cbase = c * MTF_CHUNK;
+    if (cbase >= n) return;
+    const int lane = lane_id();
+    const u8 *src = bwt + (size_t)b * S;
+    u32 L;
+    if (REPLAY) L = ((const u32 *)(mtfrec + ((size_t)b * CPB + c) * 256))[lane];
+    else L = identity_list();
+    u32 seen = 0;
+    u32 prev = 0xffffffffu;
+    const u32 cend = min(cbase + MTF_CHUNK, n);
+    for (u32 rowbase = cbase; rowbase < cend; rowbase += 64) {
+        u32 j = rowbase + lane;
+        u32 sym = (j < cend) ? smap[src[j]] : 0;
+        u32 mypos = 0;
+        const int cnt = (int)min(64u, cend - rowbase);
+        for (int i = 0; i < cnt; i++) {
+            u32 s = __builtin_amdgcn_readlane(sym, i);
+            u32 pos = 0;
+            if (s != prev) {
+                pos = mtf_step(L, s);
+                prev = s;
+                if (!REPLAY) {
+                    if ((s >> 2) == (u32)lane) seen |= 1u << (s & 3);
+                }
+            }
+            if (REPLAY) {
+                if (lane == i) mypos = pos;
+            }
+        }
+        if (REPLAY) {
+            if (j < cend) mtfpos[(size_t)b * S + j] = (u8)mypos;
+        }
+    }
+    if (!REPLAY) {
+        ((u32 *)(mtfrec + ((size_t)b * CPB + c) * 256))[lane] = L;
+        u32 d = wave_reduce_add(__popc(seen));
+        if (lane == 0) mtfcnt[(size_t)b * CPB + c] = d;
+    }
+}
+
+// one wave per block: turn recency lists into entry states, in place
+__global__ __launch_bounds__(64) void k3_mtf_compose(const u32 *__restrict__ nArr,
+                                                     u8 *__restrict__ mtfrec,
+                                                     const u32 *__restrict__ mtfcnt, u32 CPB) {
+    const u32 b = blockIdx.x;
+    const u32 n = nArr[b];
+    const u32 chunks = (n + MTF_CHUNK - 1) / MTF_CHUNK;
+    const int lane = lane_id();
+    __shared__ u8 st[256];
+    __shared__ u8 nst[256];
+    __shared__ u8 flag[256];
+    ((u32 *)st)[lane] = identity_list();
+    __syncthreads();
+    for (u32 c = 0; c < chunks; c++) {
+        u32 *slot = (u32 *)(mtfrec + ((size_t)b * CPB + c) * 256);
+        u32 rec = slot[lane];               // recency list of chunk c (first d entries valid)
+        const u32 d = mtfcnt[(size_t)b * CPB + c];
+        slot[lane] = ((u32 *)st)[lane];     // entry state of chunk c
+        if (c + 1 == chunks) break;
+        ((u32 *)flag)[lane] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            u32 p = lane * 4 + k;
+            if (p < d) {
+                u8 v = (u8)(rec >> (8 * k));
+                flag[v] = 1;
+                nst[p] = v;
+            }
+        }
+        __syncthreads();
+        u32 cur = ((u32 *)st)[lane];
+        u32 keepcnt = 0;
+        bool keep[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            keep[k] = flag[(cur >> (8 * k)) & 255u] == 0;
+            keepcnt += keep[k] ? 1u : 0u;
+        }
+        u32 inc = wave_incl_scan_add(keepcnt);
+        u32 o = d + inc - keepcnt;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (keep[k]) nst[o++] = (u8)(cur >> (8 * k));
+        }
+        __syncthreads();
+        ((u32 *)st)[lane] = ((u32 *)nst)[lane];
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ RLE2
+__device__ __forceinline__ u32 ndigits(u32 r) { return 31u - __clz(r + 1u); } // floor(log2(r+1))
+
+// element j in [0, n]: j == n is the virtual EOB (non-zero)
+// phase 1: tile summary {lz, tz, inner, allzero}
+__global__ __launch_bounds__(256) void k3_rle2_p1(const u8 *__restrict__ mtfpos,
+                                                  const u32 *__restrict__ nArr,
+                                                  u32 *__restrict__ r2agg, u32 S, u32 TPB) {
+    const u32 b = blockIdx.y;
+    const u32 n = nArr[b];
+    const u32 base = blockIdx.x * R2TILE;
+    if (base > n) return;
+    const u32 end = min(base + R2TILE, n + 1);
+    const int w = wave_id(), lane = lane_id();
+    __shared__ u32 wfirst[4], wlast[4], winner[4];
+    const u8 *mp = mtfpos + (size_t)b * S;
+    // per wave: rows of 64 elements in its 1024-element range
+    u32 first = 0xffffffffu, last = 0; // position+1 of last non-zero seen (0 = none)
+    u32 inner = 0;
+#pragma unroll 4
+    for (int k = 0; k < 16; k++) {
+        u32 rowbase = base + w * 1024 + k * 64;
+        u32 j = rowbase + lane;
+        bool nz = (j < end) && (j == n || mp[j] != 0);
+        u64 m = __ballot(nz);
+        if (m == 0) continue;
+        // previous non-zero for this lane: inside row, else `last`
+        u64 below = m & ((1ull << lane) - 1ull);
+        u32 prevp1 = below ? (rowbase + (63 - __clzll((unsigned long long)below)) + 1) : last;
+        if (nz) {
+            u32 e = 1;
+            if (prevp1 != 0) { // previous non-zero known inside this wave's range
+                u32 r = j - prevp1;
+                if (r > 0) e += ndigits(r);
+            }
+            inner += e;
+        }
+        if (first == 0xffffffffu) first = rowbase + (__ffsll((unsigned long long)m) - 1);
+        last = rowbase + (63 - __clzll((unsigned long long)m)) + 1;
+    }
+    inner = wave_reduce_add(inner);
+    if (lane == 0) {
+        wfirst[w] = first;
+        wlast[w] = last;
+        winner[w] = inner;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // stitch the 4 wave ranges: a wave's first non-zero whose run started in an earlier wave
+        u32 tot = 0, tl = 0, tf = 0xffffffffu;
+        for (int q = 0; q < 4; q++) {
+            tot += winner[q];
+            if (wfirst[q] != 0xffffffffu) {
+                if (tl != 0) {
+                    u32 r = wfirst[q] - tl;
+                    if (r > 0) tot += ndigits(r);
+                }
+                if (tf == 0xffffffffu) tf = wfirst[q];
+                tl = wlast[q];
+            }
+        }
+        u32 cnt = end - base;
+        u32 az = (tf == 0xffffffffu) ? 1u : 0u;
+        u32 lz = az ? cnt : (tf - base);
+        u32 tz = az ? cnt : (end - tl);
+        u32 *o = r2agg + ((size_t)b * TPB + blockIdx.x) * 4;
+        o[0] = lz; o[1] = tz; o[2] = tot; o[3] = az;
+    }
+}
+
+// phase 2: one workgroup per block; serial walk over tile summaries -> {offset, carry_in}
+__global__ __launch_bounds__(256) void k3_rle2_p2(const u32 *__restrict__ nArr,
+                                                  const u32 *__restrict__ present,
+                                                  u32 *__restrict__ r2agg, u32 *__restrict__ mtflen,
+                                                  u32 *__restrict__ alpha, u32 *__restrict__ freq,
+                                                  u32 TPB) {
+    const u32 b = blockIdx.x;
+    const u32 n = nArr[b];
+    const u32 tiles = n / R2TILE + 1; // elements 0..n
+    __shared__ u32 sm[256 * 4];
+    u32 *g = r2agg + (size_t)b * TPB * 4;
+    for (u32 i = threadIdx.x; i < 264; i += 256) freq[b * 264 + i] = 0;
+    u32 off = 0, carry = 0;
+    for (u32 t0 = 0; t0 < tiles; t0 += 256) {
+        u32 cnt = min(256u, tiles - t0);
+        __syncthreads();
+        for (u32 i = threadIdx.x; i < cnt * 4; i += 256) sm[i] = g[(size_t)t0 * 4 + i];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (u32 t = 0; t < cnt; t++) {
+                u32 lz = sm[t * 4], tz = sm[t * 4 + 1], inner = sm[t * 4 + 2], az = sm[t * 4 + 3];
+                sm[t * 4] = off;
+                sm[t * 4 + 1] = carry;
+                if (az) {
+                    carry += lz;
+                } else {
+                    u32 r = carry + lz;
+                    off += inner + (r > 0 ? ndigits(r) : 0u);
+                    carry = tz;
+                }
+            }
+        }
+        __syncthreads();
+        for (u32 i = threadIdx.x; i < cnt * 4; i += 256) g[(size_t)t0 * 4 + i] = sm[i];
+    }
+    if (threadIdx.x == 0) {
+        mtflen[b] = off;
+        u32 uniq = 0;
+        for (int q = 0; q < 8; q++) uniq += __popc(present[b * 8 + q]);
+        alpha[b] = uniq + 2;
+    }
+}
+
+// phase 3: write symbols + frequencies
+__global__ __launch_bounds__(256) void k3_rle2_p3(const u8 *__restrict__ mtfpos,
+                                                  const u32 *__restrict__ nArr,
+                                                  const u32 *__restrict__ r2agg,
+                                                  const u32 *__restrict__ alpha,
+                                                  u16 *__restrict__ mtf, u32 *__restrict__ freq,
+                                                  u32 S, u32 S2, u32 TPB) {
+    const u32 b = blockIdx.y;
+    const u32 n = nArr[b];
+    const u32 base = blockIdx.x * R2TILE;
+    if (base > n) return;
+    const u32 end = min(base + R2TILE, n + 1);
+    const int w = wave_id(), lane = lane_id();
+    __shared__ u32 wfirst[4], wlast[4], wsum[4];
+    __shared__ u32 hist[264];
+    for (u32 i = threadIdx.x; i < 264; i += 256) hist[i] = 0;
+    const u8 *mp = mtfpos + (size_t)b * S;
+    const u32 *ag = r2agg + ((size_t)b * TPB + blockIdx.x) * 4;
+    const u32 tile_off = ag[0], carry_in = ag[1];
+    const u32 eob = alpha[b] - 1;
+    // pass A: per wave first/last non-zero
+    u64 hm[16];
+    u32 myv[16];
+    u32 first = 0xffffffffu, last = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        u32 rowbase = base + w * 1024 + k * 64;
+        u32 j = rowbase + lane;
+        u32 v = 0;
+        if (j < end) v = (j == n) ? 0xffffu : mp[j];
+        myv[k] = v;
+        u64 m = __ballot(v != 0);
+        hm[k] = m;
+        if (m) {
+            if (first == 0xffffffffu) first = rowbase + (__ffsll((unsigned long long)m) - 1);
+            last = rowbase + (63 - __clzll((unsigned long long)m)) + 1;
+        }
+    }
+    if (lane == 0) {
+        wfirst[w] = first;
+        wlast[w] = last;
+    }
+    __syncthreads();
+    // previous non-zero (+1) before this wave's range inside the tile; 0 = none in tile
+    u32 prev_in_tile = 0;
+    for (int q = 0; q < w; q++)
+        if (wlast[q]) prev_in_tile = wlast[q];
+    // pass B: emit counts per element, wave-level sums
+    u32 ecnt[16];
+    u32 runlen[16];
+    u32 lastp1 = prev_in_tile;
+    u32 wtotal = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        u32 rowbase = base + w * 1024 + k * 64;
+        u32 j = rowbase + lane;
+        u64 m = hm[k];
+        u32 e = 0, r = 0;
+        if (m) {
+            u64 below = m & ((1ull << lane) - 1ull);
+            u32 prevp1 = below ? (rowbase + (63 - __clzll((unsigned long long)below)) + 1) : lastp1;
+            if (myv[k] != 0) {
+                if (prevp1 != 0) r = j - prevp1;
+                else r = carry_in + (j - base); // run reaches the tile start
+                e = 1 + (r > 0 ? ndigits(r) : 0u);
+            }
+            lastp1 = rowbase + (63 - __clzll((unsigned long long)m)) + 1;
+        }
+        ecnt[k] = e;
+        runlen[k] = r;
+        wtotal += e;
+    }
+    wtotal = wave_reduce_add(wtotal);
+    if (lane == 0) wsum[w] = wtotal;
+    __syncthreads();
+    u32 run = tile_off;
+    for (int q = 0; q < w; q++) run += wsum[q];
+    u16 *out = mtf + (size_t)b * S2;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        u32 e = ecnt[k];
+        u32 inc = wave_incl_scan_add(e);
+        u32 o = run + inc - e;
+        run += __shfl(inc, 63, 64);
+        if (e) {
+            u32 r = runlen[k];
+            if (r > 0) { // java:83-99
+                u32 rep = r - 1;
+                for (;;) {
+                    u32 dgt = rep & 1u;
+                    out[o++] = (u16)dgt;
+                    atomicAdd(&hist[dgt], 1u);
+                    if (rep <= 1) break;
+                    rep = (rep - 2) >> 1;
+                }
+            }
+            u32 sym = (myv[k] == 0xffffu) ? eob : (myv[k] + 1);
+            out[o] = (u16)sym;
+            atomicAdd(&hist[sym], 1u);
+        }
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < 264; i += 256) {
+        u32 c = hist[i];
+        if (c) atomicAdd(&freq[b * 264 + i], c);
+    }
+}
+
+void run_mtf(bz2hip_ctx *c, int nb, u32 maxn) {
+    Batch &B = c->batch;
+    if (nb == 0) return;
+    const u32 CPB = B.S / MTF_CHUNK;
+    const u32 chunks = (maxn + MTF_CHUNK - 1) / MTF_CHUNK;
+    dim3 gridc((chunks + MTF_WG_CHUNKS - 1) / MTF_WG_CHUNKS, nb);
+    {
+        ProfScope ps(c, P_MTF_STATE);
+        k3_mtf_chunks<false><<<gridc, 256, 0, c->stream>>>(B.bwt, B.n, B.present, B.mtfrec, B.mtfcnt,
+                                                            B.mtfpos, B.S, CPB);
+        KCHECK();
+    }
+    {
+        ProfScope ps(c, P_MTF_COMPOSE);
+        k3_mtf_compose<<<nb, 64, 0, c->stream>>>(B.n, B.mtfrec, B.mtfcnt, CPB);
+        KCHECK();
+    }
+    {
+        ProfScope ps(c, P_MTF_REPLAY);
+        k3_mtf_chunks<true><<<gridc, 256, 0, c->stream>>>(B.bwt, B.n, B.present, B.mtfrec, B.mtfcnt,
+                                                           B.mtfpos, B.S, CPB);
+        KCHECK();
+    }
+    {
+        ProfScope ps(c, P_RLE2);
+        const u32 tiles = maxn / R2TILE + 1;
+        dim3 grid(tiles, nb);
+        k3_rle2_p1<<<grid, 256, 0, c->stream>>>(B.mtfpos, B.n, B.r2agg, B.S, B.TPB);
+        KCHECK();
+        k3_rle2_p2<<<nb, 256, 0, c->stream>>>(B.n, B.present, B.r2agg, B.mtflen, B.alpha, B.freq,
+                                              B.TPB);
+        KCHECK();
+        k3_rle2_p3<<<grid, 256, 0, c->stream>>>(B.mtfpos, B.n, B.r2agg, B.alpha, B.mtf, B.freq, B.S,
+                                                B.S + 64, B.TPB);
+        KCHECK();
+    }
+}

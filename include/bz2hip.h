@@ -1,0 +1,128 @@
+/*
+ * bz2hip.h -- C ABI of libbz2hip: the MI355X (gfx950) bzip2 block compressor.
+ *
+ * This is the drop-in boundary for the hot path of bastie/bzip2 (Swift port of jbzip2):
+ * everything below BZip2OutputStream.closeBlock() plus the RLE1/CRC ingest loop.  The
+ * reference has no FFI of its own (pure Swift); each entry point cites the reference
+ * interface it replaces ("S/" = Sources/bzip2JavApi/).  Plain pointers and sizes only.
+ *
+ * Conventions: every function returns BZ2HIP_OK (0) or a negative error code and never
+ * throws; bz2hip_last_error() gives the message.  A context is bound to one GPU and is not
+ * thread-safe (the reference streams are not either: S/BZip2OutputStream.swift:29).
+ * Pointers named d_* are device (HBM) pointers on the context's GPU; all others are host.
+ */
+#ifndef BZ2HIP_H
+#define BZ2HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BZ2HIP_OK 0
+#define BZ2HIP_E_PARAM (-1)   /* bad argument (level outside 1..9, null pointer, ...) */
+#define BZ2HIP_E_NOMEM (-2)   /* device or host allocation failed */
+#define BZ2HIP_E_HIP (-3)     /* a HIP runtime call failed */
+#define BZ2HIP_E_CAP (-4)     /* caller's output buffer too small */
+#define BZ2HIP_E_STATE (-5)   /* call sequence error, e.g. write after finish */
+
+#define BZ2HIP_MAX_ALPHA 258
+#define BZ2HIP_MAX_TABLES 6
+
+typedef struct bz2hip_ctx bz2hip_ctx;
+
+typedef struct bz2hip_opts {
+    int device;            /* HIP device ordinal; -1 = current device */
+    int max_batch_blocks;  /* blocks sorted per batch (0 = default 256) */
+    int tie_rule;          /* origin-pointer rule on periodic blocks (0 = default) */
+    int profile;           /* 1 = record HIP events per kernel class (bz2hip_profile_*) */
+} bz2hip_opts;
+
+/* Context life cycle (no counterpart in the reference; holds the GPU workspace). */
+int bz2hip_create(bz2hip_ctx **ctx, const bz2hip_opts *opts);
+void bz2hip_destroy(bz2hip_ctx *ctx);
+const char *bz2hip_last_error(const bz2hip_ctx *ctx);
+const char *bz2hip_version(void);
+
+/* Upper bound of the compressed size of n input bytes (stream header + trailer included). */
+size_t bz2hip_compress_bound(size_t n);
+
+/* ---- whole-stream entry points -------------------------------------------------------
+ * Replace BZip2OutputStream(out, level); write(data, 0, n); close()
+ * (S/BZip2OutputStream.swift:85-104,110-113,149-161,171-189).  Output is the complete
+ * .bz2 stream ("BZh" + level, blocks, end marker, stream CRC, zero pad). */
+int bz2hip_compress(bz2hip_ctx *ctx, const uint8_t *in, size_t n, int level, uint8_t *out,
+                    size_t cap, size_t *out_len);
+/* Same with input and output resident in HBM (no PCIe transfer). */
+int bz2hip_compress_device(bz2hip_ctx *ctx, const void *d_in, size_t n, int level, void *d_out,
+                           size_t cap, size_t *out_len);
+
+/* ---- streaming entry points ----------------------------------------------------------
+ * bz2hip_stream_begin  = BZip2OutputStream.init        S/BZip2OutputStream.swift:171-189
+ * bz2hip_stream_write  = write([UInt8], off, len)      :85-104 (buffers; blocks are cut by the
+ *                        RLE1 acceptance rule of BZip2BlockCompressor.write :198-227)
+ * bz2hip_stream_finish = finish()                      :149-161
+ * bz2hip_stream_read   drains compressed bytes in stream order (the bytes the reference would
+ *                        have passed to java.io.OutputStream.write, S/BZip2BitOutputStream.swift:58,93)
+ * Writing after finish returns BZ2HIP_E_STATE ("Write beyond end of stream", :69-71,89-91). */
+int bz2hip_stream_begin(bz2hip_ctx *ctx, int level);
+int bz2hip_stream_write(bz2hip_ctx *ctx, const uint8_t *p, size_t n);
+int bz2hip_stream_finish(bz2hip_ctx *ctx);
+int bz2hip_stream_read(bz2hip_ctx *ctx, uint8_t *out, size_t cap, size_t *produced);
+size_t bz2hip_stream_pending(const bz2hip_ctx *ctx);
+
+/* ---- block / stage entry points (host pointers; batched over `count` blocks) ---------
+ * Blocks are laid out at `stride` bytes (or elements) from each other. */
+
+/* Block boundaries + RLE1 + CRC: BZip2BlockCompressor.write/writeRun
+ * (S/BZip2BlockCompressor.swift:151-252) and BZip2CRC32 (S/BZip2CRC32.swift:76-105).
+ * starts[b] = input offset of block b; rle (stride level*100000+8) receives the RLE1 blocks. */
+int bz2hip_rle1_split(bz2hip_ctx *ctx, const uint8_t *in, size_t n, int level,
+                      uint32_t max_blocks, uint32_t *n_blocks, uint64_t *starts,
+                      uint8_t *rle, uint32_t *rle_len, uint8_t *present /*[b][256]*/,
+                      uint32_t *crc);
+
+/* BZip2DivSufSort(T, SA, n).bwt()  S/BZip2DivSufSort.swift:3487-3518: last column of the sorted
+ * cyclic rotations and the origin pointer.  rounds (optional) = doubling rounds executed. */
+int bz2hip_bwt(bz2hip_ctx *ctx, const uint8_t *blocks, const uint32_t *n, uint32_t count,
+               uint32_t stride, uint8_t *bwt, uint32_t *orig, uint32_t *rounds);
+
+/* BZip2MTFAndRLE2StageEncoder(bwt, n, present).encode() + getters
+ * (S/BZip2MTFAndRLE2StageEncoder.swift:43-163).  mtf has stride+2 elements per block. */
+int bz2hip_mtf_rle2(bz2hip_ctx *ctx, const uint8_t *bwt, const uint32_t *n, uint32_t count,
+                    uint32_t stride, const uint8_t *present, uint16_t *mtf, uint32_t *mtf_len,
+                    uint32_t *alpha, int32_t *freq /*[b][258]*/);
+
+/* BZip2HuffmanStageEncoder: selectTableCount, generateHuffmanOptimisationSeeds, 4x
+ * optimiseSelectorsAndHuffmanTables (S/BZip2HuffmanStageEncoder.swift:82-98,144-248,360-366)
+ * incl. HuffmanAllocator.allocateHuffmanCodeLengths (S/BZip2HuffmanAllocator.swift:197-223).
+ * lengths is [b][6][258] (int32), selectors has sel_stride bytes per block. */
+int bz2hip_huffman(bz2hip_ctx *ctx, const uint16_t *mtf, const uint32_t *mtf_len,
+                   const uint32_t *alpha, const int32_t *freq, uint32_t count, uint32_t stride,
+                   uint32_t *n_tables, int32_t *lengths, uint8_t *selectors,
+                   uint32_t sel_stride, uint32_t *n_selectors);
+
+/* BZip2BlockCompressor.close() S/BZip2BlockCompressor.swift:258-289 for `count` RLE1'd blocks:
+ * BWT, header, symbol map, MTF/RLE2, Huffman, bit packing.  Each block's bits start at bit 0
+ * (MSB first) of bits + b*bits_stride; nbits[b] = exact bit length. */
+int bz2hip_block_compress(bz2hip_ctx *ctx, const uint8_t *rle_blocks, const uint32_t *n,
+                          uint32_t count, uint32_t stride, const uint8_t *present,
+                          const uint32_t *crc, uint8_t *bits, size_t bits_stride,
+                          uint64_t *nbits);
+
+/* ---- profiling (profile=1): accumulated HIP-event time per kernel class --------------- */
+#define BZ2HIP_PROF_MAX 48
+int bz2hip_profile_reset(bz2hip_ctx *ctx);
+/* names[i], ms[i], launches[i], bytes[i] (algorithmic bytes) for i < *count */
+int bz2hip_profile_get(bz2hip_ctx *ctx, int *count, const char **names, double *ms,
+                       uint64_t *launches, double *alg_bytes);
+/* doubling rounds summed over blocks and block count of the last compress call */
+int bz2hip_last_stats(bz2hip_ctx *ctx, uint64_t *blocks, uint64_t *rounds_sum,
+                      uint64_t *rle_bytes, uint64_t *periodic_blocks);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
