@@ -21,7 +21,7 @@ SYMBOLS = [
     "bz2hip_stream_begin", "bz2hip_stream_write", "bz2hip_stream_finish", "bz2hip_stream_read",
     "bz2hip_stream_pending", "bz2hip_rle1_split", "bz2hip_bwt", "bz2hip_mtf_rle2",
     "bz2hip_huffman", "bz2hip_block_compress", "bz2hip_profile_reset", "bz2hip_profile_get",
-    "bz2hip_last_stats",
+    "bz2hip_last_stats", "bz2hip_last_stats2",
 ]
 
 
@@ -89,6 +89,8 @@ def load():
     L.bz2hip_profile_get.argtypes = [vp, C.POINTER(C.c_int), vp, vp, vp, vp]
     L.bz2hip_last_stats.restype = C.c_int
     L.bz2hip_last_stats.argtypes = [vp, vp, vp, vp, vp]
+    L.bz2hip_last_stats2.restype = C.c_int
+    L.bz2hip_last_stats2.argtypes = [vp, vp, vp]
     _lib = L
     return L
 
@@ -255,10 +257,14 @@ class Context:
         launches = (C.c_uint64 * 48)()
         ab = (C.c_double * 48)()
         self.L.bz2hip_profile_get(self.h, C.byref(cnt), names, ms, launches, ab)
-        return {names[i].decode(): {"ms": ms[i], "launches": launches[i]} for i in range(cnt.value)}
+        return {names[i].decode(): {"ms": ms[i], "launches": launches[i], "alg_bytes": ab[i]}
+                for i in range(cnt.value)}
 
     def last_stats(self):
         v = [C.c_uint64(0) for _ in range(4)]
         self.L.bz2hip_last_stats(self.h, *[C.byref(x) for x in v])
+        w = [C.c_uint64(0), C.c_uint64(0)]
+        self.L.bz2hip_last_stats2(self.h, C.byref(w[0]), C.byref(w[1]))
         return {"blocks": v[0].value, "rounds_sum": v[1].value, "rle_bytes": v[2].value,
-                "periodic_blocks": v[3].value}
+                "periodic_blocks": v[3].value, "n_times_rounds": w[0].value,
+                "sorted_elems": w[1].value}

@@ -227,6 +227,7 @@ static size_t compress_core(bz2hip_ctx *c, const u8 *d_in, size_t n, int level, 
     size_t pos = 0;
     bool wrote_header = !header;
     c->st_blocks = c->st_rounds = c->st_rle_bytes = c->st_periodic = 0;
+    c->st_sorted_elems = c->st_nr = 0;
     std::vector<u32> starts;
     bool any_frame = false;
     while (pos < n) {
@@ -270,6 +271,7 @@ static size_t compress_core(bz2hip_ctx *c, const u8 *d_in, size_t n, int level, 
                 c->st_blocks++;
                 c->st_rounds += hr[b];
                 c->st_rle_bytes += hn[b];
+                c->st_nr += (u64)hn[b] * hr[b];
                 if (hp[b] > 1) c->st_periodic++;
             }
         }
@@ -639,6 +641,13 @@ extern "C" int bz2hip_profile_get(bz2hip_ctx *c, int *count, const char **names,
         if (launches) launches[i] = c->prof_launches[i];
         if (alg_bytes) alg_bytes[i] = c->prof_bytes[i];
     }
+    return BZ2HIP_OK;
+}
+
+extern "C" int bz2hip_last_stats2(bz2hip_ctx *c, uint64_t *n_times_rounds, uint64_t *sorted_elems) {
+    if (!c) return BZ2HIP_E_PARAM;
+    if (n_times_rounds) *n_times_rounds = c->st_nr;
+    if (sorted_elems) *sorted_elems = c->st_sorted_elems;
     return BZ2HIP_OK;
 }
 

@@ -104,6 +104,8 @@ struct bz2hip_ctx {
     double prof_bytes[P_COUNT] = {0};
     // stats of the last call
     u64 st_blocks = 0, st_rounds = 0, st_rle_bytes = 0, st_periodic = 0;
+    u64 st_sorted_elems = 0; // sum over radix passes of elements moved
+    u64 st_nr = 0;           // sum over blocks of n_b * doubling rounds_b
     // streaming state
     int s_level = 0;
     bool s_open = false, s_finished = false;

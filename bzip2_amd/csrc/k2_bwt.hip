@@ -304,6 +304,7 @@ __global__ void k2_round_ctl(const u32 *__restrict__ nArr, u32 *__restrict__ nhe
         rounds[b] += 1;
         nheads[b] = 0;
         atomicOr(&ctl[0], 1u);
+        atomicAdd(&ctl[1], n); // elements sorted in the coming round (for the roofline figure)
     } else {
         active[b] = 0;
         periodic[b] = (heads < n) ? (n / heads) : 1;
@@ -365,8 +366,8 @@ __global__ __launch_bounds__(RT_THREADS) void k2_emit_bwt(
 __global__ void k2_reset(const u32 *__restrict__ nArr, u32 *nheads, u32 *active, u32 *rounds,
                          u32 *periodic, u32 *ctl, u32 nb) {
     u32 b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b == 0) ctl[0] = 0;
     if (b >= nb) return;
+    atomicAdd(&ctl[2], nArr[b]);
     nheads[b] = 0;
     active[b] = nArr[b] > 0 ? 1 : 0;
     rounds[b] = 0;
@@ -425,6 +426,7 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
     const u32 tiles = (maxn + RTILE - 1) / RTILE;
     dim3 grid(tiles, nb);
     const int cb = (nb + 255) / 256;
+    HIPCHK(hipMemsetAsync(B.ctl, 0, 4 * sizeof(u32), c->stream));
     k2_reset<<<cb, 256, 0, c->stream>>>(B.n, B.nheads, B.active, B.rounds, B.periodic, B.ctl, nb);
     KCHECK();
     {
@@ -438,14 +440,23 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
     rerank(c, nb, maxn, kin, vin);
     u32 h = 8;
     for (;;) {
-        HIPCHK(hipMemsetAsync(B.ctl, 0, sizeof(u32), c->stream));
+        HIPCHK(hipMemsetAsync(B.ctl, 0, 2 * sizeof(u32), c->stream));
         k2_round_ctl<<<cb, 256, 0, c->stream>>>(B.n, B.nheads, B.active, B.rounds, B.periodic, B.ctl,
                                                 nb, h);
         KCHECK();
-        u32 any = 0;
-        HIPCHK(hipMemcpyAsync(&any, B.ctl, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+        u32 hc[3] = {0, 0, 0};
+        HIPCHK(hipMemcpyAsync(hc, B.ctl, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
-        if (!any) break;
+        if (h == 8 && c->profile) { // round 0 sorted every element: 8 passes of 24 B
+            c->prof_bytes[P_RADIX_SCATTER] += 8.0 * 24.0 * (double)hc[2];
+            c->prof_bytes[P_RADIX_HIST] += 8.0 * 8.0 * (double)hc[2];
+        }
+        c->st_sorted_elems += (h == 8 ? (u64)hc[2] * 8 : 0) + (u64)hc[1] * (hc[0] ? 5 : 0);
+        if (!hc[0]) break;
+        if (c->profile) {
+            c->prof_bytes[P_RADIX_SCATTER] += 5.0 * 24.0 * (double)hc[1];
+            c->prof_bytes[P_RADIX_HIST] += 5.0 * 8.0 * (double)hc[1];
+        }
         {
             ProfScope ps(c, P_BWT_KEYS);
             k2_build_keys<<<grid, RT_THREADS, 0, c->stream>>>(B.sa, B.grp, B.rank, B.n, B.active,

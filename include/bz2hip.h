@@ -122,6 +122,9 @@ int bz2hip_profile_get(bz2hip_ctx *ctx, int *count, const char **names, double *
 int bz2hip_last_stats(bz2hip_ctx *ctx, uint64_t *blocks, uint64_t *rounds_sum,
                       uint64_t *rle_bytes, uint64_t *periodic_blocks);
 
+/* sum over blocks of n_b * rounds_b, and elements moved summed over all radix passes */
+int bz2hip_last_stats2(bz2hip_ctx *ctx, uint64_t *n_times_rounds, uint64_t *sorted_elems);
+
 #ifdef __cplusplus
 }
 #endif
