@@ -108,7 +108,8 @@ class Context:
         o = Opts(device, max_batch_blocks, tie_rule, 1 if profile else 0)
         rc = self.L.bz2hip_create(C.byref(self.h), C.byref(o))
         if rc != OK:
-            raise BZ2HipError(rc, "bz2hip_create failed (no GPU / HIP runtime?)")
+            raise BZ2HipError(rc, "bz2hip_create failed: " +
+                              self.L.bz2hip_last_error(None).decode())
 
     def close(self):
         if self.h:

@@ -171,11 +171,17 @@ extern "C" size_t bz2hip_compress_bound(size_t n) {
     return n + n / 4 + 4096 + (n / 100000 + 1) * 2600;
 }
 
+static std::string g_create_err = "no error";
+
 extern "C" int bz2hip_create(bz2hip_ctx **out, const bz2hip_opts *opts) {
     if (!out) return BZ2HIP_E_PARAM;
     *out = nullptr;
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return BZ2HIP_E_HIP;
+    hipError_t e0 = hipGetDeviceCount(&ndev);
+    if (e0 != hipSuccess || ndev == 0) {
+        g_create_err = std::string("hipGetDeviceCount: ") + hipGetErrorString(e0);
+        return BZ2HIP_E_HIP;
+    }
     bz2hip_ctx *c = new (std::nothrow) bz2hip_ctx();
     if (!c) return BZ2HIP_E_NOMEM;
     if (opts) c->opts = *opts;
@@ -188,13 +194,15 @@ extern "C" int bz2hip_create(bz2hip_ctx **out, const bz2hip_opts *opts) {
     c->device = dev;
     c->profile = c->opts.profile != 0;
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
+        g_create_err = "hipSetDevice/hipStreamCreate failed";
         delete c;
         return BZ2HIP_E_HIP;
     }
     try {
         k1_init_tables(c);
-    } catch (const std::exception &) {
-        hipStreamDestroy(c->stream);
+    } catch (const std::exception &e) {
+        g_create_err = e.what();
+        (void)hipStreamDestroy(c->stream);
         delete c;
         return BZ2HIP_E_HIP;
     }
@@ -216,7 +224,9 @@ extern "C" void bz2hip_destroy(bz2hip_ctx *c) {
     delete c;
 }
 
-extern "C" const char *bz2hip_last_error(const bz2hip_ctx *c) { return c ? c->err.c_str() : "null context"; }
+extern "C" const char *bz2hip_last_error(const bz2hip_ctx *c) {
+    return c ? c->err.c_str() : g_create_err.c_str(); // NULL: error of the last failed create
+}
 
 // ------------------------------------------------------------------ the pipeline
 // Compresses blocks of d_in[0..n) into d_out (zeroed by the caller up to out_cap) starting at
