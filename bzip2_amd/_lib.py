@@ -18,6 +18,7 @@ MAX_ALPHA, MAX_TABLES = 258, 6
 SYMBOLS = [
     "bz2hip_create", "bz2hip_destroy", "bz2hip_last_error", "bz2hip_version",
     "bz2hip_compress_bound", "bz2hip_compress", "bz2hip_compress_device",
+    "bz2hip_compress_blocks_device", "bz2hip_compress_blocks", "bz2hip_stitch",
     "bz2hip_stream_begin", "bz2hip_stream_write", "bz2hip_stream_finish", "bz2hip_stream_read",
     "bz2hip_stream_pending", "bz2hip_rle1_split", "bz2hip_bwt", "bz2hip_mtf_rle2",
     "bz2hip_huffman", "bz2hip_block_compress", "bz2hip_profile_reset", "bz2hip_profile_get",
@@ -62,6 +63,12 @@ def load():
     L.bz2hip_compress.argtypes = [vp, vp, sz, C.c_int, vp, sz, C.POINTER(sz)]
     L.bz2hip_compress_device.restype = C.c_int
     L.bz2hip_compress_device.argtypes = [vp, vp, sz, C.c_int, vp, sz, C.POINTER(sz)]
+    L.bz2hip_compress_blocks_device.restype = C.c_int
+    L.bz2hip_compress_blocks_device.argtypes = [vp, vp, sz, C.c_int, vp, sz, vp, vp, C.c_uint32, u32p]
+    L.bz2hip_compress_blocks.restype = C.c_int
+    L.bz2hip_compress_blocks.argtypes = [vp, vp, sz, C.c_int, vp, sz, vp, vp, C.c_uint32, u32p]
+    L.bz2hip_stitch.restype = C.c_int
+    L.bz2hip_stitch.argtypes = [C.c_int, C.c_uint32, vp, vp, vp, vp, vp, sz, C.POINTER(sz)]
     L.bz2hip_stream_begin.restype = C.c_int
     L.bz2hip_stream_begin.argtypes = [vp, C.c_int]
     L.bz2hip_stream_write.restype = C.c_int
@@ -97,6 +104,28 @@ def load():
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def stitch(level, segments):
+    """segments: list of (bits: uint8 array/bytes, nbits, crcs: uint32 array) in block order.
+    Returns the complete .bz2 stream (host-side ordered concatenation, bz2hip_stitch)."""
+    L = load()
+    n = len(segments)
+    bits = [np.ascontiguousarray(np.frombuffer(bytes(s[0]), dtype=np.uint8) if not isinstance(s[0], np.ndarray) else s[0], dtype=np.uint8) for s in segments]
+    bits = [b if b.size else np.zeros(1, dtype=np.uint8) for b in bits]
+    crcs = [np.ascontiguousarray(s[2], dtype=np.uint32) for s in segments]
+    crcs_nz = [c if c.size else np.zeros(1, dtype=np.uint32) for c in crcs]
+    pb = (C.c_void_p * max(n, 1))(*[b.ctypes.data for b in bits])
+    pc = (C.c_void_p * max(n, 1))(*[c.ctypes.data for c in crcs_nz])
+    nbits = np.array([int(s[1]) for s in segments] + [0], dtype=np.uint64)
+    ncrc = np.array([c.size for c in crcs] + [0], dtype=np.uint32)
+    cap = int(nbits.sum() // 8) + 64
+    out = np.empty(cap, dtype=np.uint8)
+    got = C.c_size_t(0)
+    rc = L.bz2hip_stitch(level, n, pb, _p(nbits), pc, _p(ncrc), _p(out), cap, C.byref(got))
+    if rc != OK:
+        raise BZ2HipError(rc, "bz2hip_stitch failed")
+    return out[: got.value].tobytes()
 
 
 class Context:
@@ -141,6 +170,42 @@ class Context:
         self._chk(self.L.bz2hip_compress_device(self.h, C.c_void_p(d_in_ptr), n, level,
                                                 C.c_void_p(d_out_ptr), cap, C.byref(got)))
         return got.value
+
+    def compress_blocks_device(self, d_in_ptr, n, level, d_out_ptr, cap):
+        """-> (nbits, crcs) : header/trailer-less bit segment of whole blocks"""
+        mx = n // (level * 50000) + 8
+        crcs = np.zeros(mx, dtype=np.uint32)
+        nb = C.c_uint32(0)
+        nbits = C.c_uint64(0)
+        self._chk(self.L.bz2hip_compress_blocks_device(self.h, C.c_void_p(d_in_ptr), n, level,
+                                                       C.c_void_p(d_out_ptr), cap, C.byref(nbits),
+                                                       _p(crcs), mx, C.byref(nb)))
+        return nbits.value, crcs[: nb.value].copy()
+
+    def compress_blocks(self, data, level):
+        """host data -> (bits bytes, nbits, crcs)"""
+        a = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else \
+            np.ascontiguousarray(data, dtype=np.uint8)
+        cap = self.L.bz2hip_compress_bound(a.size)
+        out = np.empty(cap, dtype=np.uint8)
+        mx = a.size // (level * 50000) + 8
+        crcs = np.zeros(mx, dtype=np.uint32)
+        nb = C.c_uint32(0)
+        nbits = C.c_uint64(0)
+        self._chk(self.L.bz2hip_compress_blocks(self.h, _p(a), a.size, level, _p(out), cap,
+                                                C.byref(nbits), _p(crcs), mx, C.byref(nb)))
+        return out[: (nbits.value + 7) // 8].copy(), nbits.value, crcs[: nb.value].copy()
+
+    def split(self, data, level):
+        """block start offsets of the stream (K1 split only)"""
+        a = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else \
+            np.ascontiguousarray(data, dtype=np.uint8)
+        mx = a.size // (level * 50000) + 8
+        nb = C.c_uint32(0)
+        starts = np.zeros(mx, dtype=np.uint64)
+        self._chk(self.L.bz2hip_rle1_split(self.h, _p(a), a.size, level, mx, C.byref(nb),
+                                           _p(starts), None, None, None, None))
+        return starts[: nb.value].copy()
 
     # ---- streaming
     def stream_begin(self, level):

@@ -232,7 +232,8 @@ extern "C" const char *bz2hip_last_error(const bz2hip_ctx *c) {
 // Compresses blocks of d_in[0..n) into d_out (zeroed by the caller up to out_cap) starting at
 // bit *bitpos.  Only complete blocks are taken unless `final`.  Returns bytes consumed.
 static size_t compress_core(bz2hip_ctx *c, const u8 *d_in, size_t n, int level, u8 *d_out,
-                            size_t out_cap, u64 *bitpos, u32 *stream_crc, bool header, bool final) {
+                            size_t out_cap, u64 *bitpos, u32 *stream_crc, bool header, bool final,
+                            bool trailer = true, std::vector<u32> *crcs_out = nullptr) {
     const u32 bs = (u32)level * 100000u;
     size_t pos = 0;
     bool wrote_header = !header;
@@ -264,7 +265,7 @@ static size_t compress_core(bz2hip_ctx *c, const u8 *d_in, size_t n, int level, 
             run_mtf(c, nb, bs);
             run_huffman(c, nb, bs + 1);
             run_pack(c, nb, bs + 1, d_out, *bitpos, false, 0, out_cap, nullptr);
-            const bool is_last = final && last_window && (b0 + nb == usable);
+            const bool is_last = final && trailer && last_window && (b0 + nb == usable);
             u64 endbit;
             u32 crc_out;
             run_frame(c, nb, d_out, level, !wrote_header, is_last, *stream_crc, &endbit, &crc_out);
@@ -272,6 +273,11 @@ static size_t compress_core(bz2hip_ctx *c, const u8 *d_in, size_t n, int level, 
             any_frame = true;
             *bitpos = endbit;
             *stream_crc = crc_out;
+            if (crcs_out) {
+                size_t o = crcs_out->size();
+                crcs_out->resize(o + nb);
+                HIPCHK(hipMemcpy(crcs_out->data() + o, B.crc, nb * sizeof(u32), hipMemcpyDeviceToHost));
+            }
             // stats
             std::vector<u32> hr(nb), hp(nb), hn(nb);
             HIPCHK(hipMemcpy(hr.data(), B.rounds, nb * sizeof(u32), hipMemcpyDeviceToHost));
@@ -288,7 +294,7 @@ static size_t compress_core(bz2hip_ctx *c, const u8 *d_in, size_t n, int level, 
         pos += starts[usable];
         if (usable < cnt && last_window) break;
     }
-    if (final && !any_frame) {
+    if (final && trailer && !any_frame) {
         // empty input (or nothing left): header and/or trailer only
         ensure_batch(c, level, 1);
         u64 bp = *bitpos;
@@ -322,6 +328,29 @@ extern "C" int bz2hip_compress_device(bz2hip_ctx *c, const void *d_in, size_t n,
     });
 }
 
+extern "C" int bz2hip_compress_blocks_device(bz2hip_ctx *c, const void *d_in, size_t n, int level,
+                                             void *d_out, size_t cap, uint64_t *nbits,
+                                             uint32_t *crcs, uint32_t max_blocks,
+                                             uint32_t *n_blocks) {
+    return guarded(c, [&]() -> int {
+        if (level < 1 || level > 9) return fail(c, BZ2HIP_E_PARAM, "Invalid BZip2 block size");
+        if (!d_out || !nbits || !crcs || !n_blocks || (n && !d_in)) return fail(c, BZ2HIP_E_PARAM, "null pointer");
+        if (((uintptr_t)d_out & 3) != 0) return fail(c, BZ2HIP_E_PARAM, "d_out must be 4-byte aligned");
+        if (cap < 64) return fail(c, BZ2HIP_E_CAP, "output buffer too small");
+        size_t zlen = std::min(cap, bz2hip_compress_bound(n)) & ~(size_t)3;
+        HIPCHK(hipMemsetAsync(d_out, 0, zlen, c->stream));
+        u64 bitpos = 0;
+        u32 scrc = 0;
+        std::vector<u32> cr;
+        compress_core(c, (const u8 *)d_in, n, level, (u8 *)d_out, zlen, &bitpos, &scrc, false, true, false, &cr);
+        if (cr.size() > max_blocks) return fail(c, BZ2HIP_E_CAP, "more blocks than max_blocks");
+        for (size_t i = 0; i < cr.size(); i++) crcs[i] = cr[i];
+        *n_blocks = (uint32_t)cr.size();
+        *nbits = bitpos;
+        return BZ2HIP_OK;
+    });
+}
+
 extern "C" int bz2hip_compress(bz2hip_ctx *c, const uint8_t *in, size_t n, int level, uint8_t *out,
                                size_t cap, size_t *out_len) {
     return guarded(c, [&]() -> int {
@@ -338,6 +367,59 @@ extern "C" int bz2hip_compress(bz2hip_ctx *c, const uint8_t *in, size_t n, int l
         *out_len = got;
         return BZ2HIP_OK;
     });
+}
+
+extern "C" int bz2hip_compress_blocks(bz2hip_ctx *c, const uint8_t *in, size_t n, int level,
+                                      uint8_t *out, size_t cap, uint64_t *nbits, uint32_t *crcs,
+                                      uint32_t max_blocks, uint32_t *n_blocks) {
+    return guarded(c, [&]() -> int {
+        if (!out || !nbits || (n && !in)) return fail(c, BZ2HIP_E_PARAM, "null pointer");
+        size_t bound = bz2hip_compress_bound(n);
+        ensure_staging(c, n, bound);
+        if (n) HIPCHK(hipMemcpyAsync(c->h_in, in, n, hipMemcpyHostToDevice, c->stream));
+        int rc = bz2hip_compress_blocks_device(c, c->h_in, n, level, c->h_out, bound, nbits, crcs,
+                                               max_blocks, n_blocks);
+        if (rc != BZ2HIP_OK) return rc;
+        size_t got = (size_t)((*nbits + 7) / 8);
+        if (got > cap) return fail(c, BZ2HIP_E_CAP, "output buffer too small");
+        if (got) HIPCHK(hipMemcpy(out, c->h_out, got, hipMemcpyDeviceToHost));
+        return BZ2HIP_OK;
+    });
+}
+
+// Host-side ordered concatenation of block segments into one stream (K8 across GPUs):
+// S/BZip2OutputStream.swift:139 (CRC fold), :154-157 (trailer), :181-184 (header),
+// S/BZip2BitOutputStream.swift:116-120 (zero pad).  Pure host code, no context needed.
+extern "C" int bz2hip_stitch(int level, uint32_t nseg, const uint8_t *const *seg_bits,
+                             const uint64_t *seg_nbits, const uint32_t *const *seg_crcs,
+                             const uint32_t *seg_ncrc, uint8_t *out, size_t cap, size_t *out_len) {
+    if (level < 1 || level > 9 || !out || !out_len) return BZ2HIP_E_PARAM;
+    u64 total = 32 + 80;
+    for (u32 i = 0; i < nseg; i++) total += seg_nbits[i];
+    if ((total + 7) / 8 > cap) return BZ2HIP_E_CAP;
+    u8 *p = out;
+    u64 acc = 0;
+    int nb = 0;
+    auto put = [&](int cnt, u32 v) {
+        acc = (acc << cnt) | (u64)(v & (cnt >= 32 ? 0xffffffffu : ((1u << cnt) - 1u)));
+        nb += cnt;
+        while (nb >= 8) { *p++ = (u8)(acc >> (nb - 8)); nb -= 8; }
+    };
+    put(16, 0x425a); put(8, 0x68); put(8, (u32)('0' + level));
+    u32 scrc = 0;
+    for (u32 i = 0; i < nseg; i++) {
+        const u8 *src = seg_bits[i];
+        u64 full = seg_nbits[i] >> 3;
+        if (nb == 0) { memcpy(p, src, full); p += full; }
+        else for (u64 k = 0; k < full; k++) put(8, src[k]);
+        int rem = (int)(seg_nbits[i] & 7);
+        if (rem) put(rem, (u32)(src[full] >> (8 - rem)));
+        for (u32 k = 0; k < seg_ncrc[i]; k++) scrc = ((scrc << 1) | (scrc >> 31)) ^ seg_crcs[i][k];
+    }
+    put(24, 0x177245); put(24, 0x385090); put(16, scrc >> 16); put(16, scrc & 0xffff);
+    if (nb > 0) { *p++ = (u8)(acc << (8 - nb)); nb = 0; }
+    *out_len = (size_t)(p - out);
+    return BZ2HIP_OK;
 }
 
 // ------------------------------------------------------------------ streaming

@@ -59,6 +59,28 @@ int bz2hip_compress(bz2hip_ctx *ctx, const uint8_t *in, size_t n, int level, uin
 int bz2hip_compress_device(bz2hip_ctx *ctx, const void *d_in, size_t n, int level, void *d_out,
                            size_t cap, size_t *out_len);
 
+/* Blocks only, for sharding one stream over several GPUs: compresses d_in[0..n) -- which must
+ * begin at a block boundary of the whole stream and end at one (or at the end of the data) --
+ * into bit-abutted blocks starting at bit 0 of d_out, without stream header or trailer.
+ * nbits = total bit length; crcs[b] = block CRCs in order (what closeBlock folds into the
+ * stream CRC, S/BZip2OutputStream.swift:131-141).  The host stitches shards in order
+ * (bzip2_amd/parallel.py). */
+int bz2hip_compress_blocks_device(bz2hip_ctx *ctx, const void *d_in, size_t n, int level,
+                                  void *d_out, size_t cap, uint64_t *nbits, uint32_t *crcs,
+                                  uint32_t max_blocks, uint32_t *n_blocks);
+
+/* Host-pointer form of the above (stages through the context's device buffers). */
+int bz2hip_compress_blocks(bz2hip_ctx *ctx, const uint8_t *in, size_t n, int level, uint8_t *out,
+                           size_t cap, uint64_t *nbits, uint32_t *crcs, uint32_t max_blocks,
+                           uint32_t *n_blocks);
+
+/* Ordered concatenation of block segments (from bz2hip_compress_blocks*) into one stream: the
+ * sequential part of BZip2OutputStream -- header :181-184, bit-abutted blocks, CRC fold :139,
+ * end marker + stream CRC + zero pad :154-157 (S/BZip2OutputStream.swift).  Host only. */
+int bz2hip_stitch(int level, uint32_t nseg, const uint8_t *const *seg_bits,
+                  const uint64_t *seg_nbits, const uint32_t *const *seg_crcs,
+                  const uint32_t *seg_ncrc, uint8_t *out, size_t cap, size_t *out_len);
+
 /* ---- streaming entry points ----------------------------------------------------------
  * bz2hip_stream_begin  = BZip2OutputStream.init        S/BZip2OutputStream.swift:171-189
  * bz2hip_stream_write  = write([UInt8], off, len)      :85-104 (buffers; blocks are cut by the

@@ -1,0 +1,213 @@
+"""CPU tests of the oracle (oracle/bz2_oracle.c): the reference has no runnable test or fixture
+(PARITY UNPINNED), so the restatement is pinned by format checks (libbz2 decode
+with CRC verification), hand-checkable constants, independent re-implementations and the frozen
+golden vectors in tests/golden/."""
+import bz2
+import hashlib
+import heapq
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from bzip2_amd import corpus
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = json.load(open(os.path.join(HERE, "golden", "golden.json")))
+
+
+def test_empty_stream_constant(orc):
+    # S/BZip2OutputStream.swift:133-135,154-156,181-184: header + end magic + CRC 0
+    out, nb = orc.compress(b"", 9)
+    assert out.hex() == "425a683917724538509000000000"
+    assert nb == 0
+
+
+def test_invalid_level(orc):
+    for lvl in (0, 10, -1):
+        with pytest.raises(ValueError):
+            orc.compress(b"abc", lvl)
+
+
+def _crc_bitwise(data):
+    crc = 0xFFFFFFFF
+    for b in data:
+        crc ^= b << 24
+        for _ in range(8):
+            crc = ((crc << 1) ^ 0x04C11DB7) & 0xFFFFFFFF if crc & 0x80000000 else (crc << 1) & 0xFFFFFFFF
+    return crc ^ 0xFFFFFFFF
+
+
+def test_crc_against_bitwise(orc):
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 2, 17, 1000):
+        d = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert orc.block_crc(d) == _crc_bitwise(d)
+    # first table entries S/BZip2CRC32.swift:34
+    assert orc.crc32(b"\x01", 0) == 0x04C11DB7
+
+
+@pytest.mark.parametrize("name", sorted(GOLDEN["small"].keys()))
+def test_golden_small(orc, name):
+    ent = GOLDEN["small"][name]
+    data = bytes.fromhex(ent["input_hex"])
+    for level, exp in ent["streams"].items():
+        out, nb = orc.compress(data, int(level))
+        assert out.hex() == exp["hex"]
+        assert nb == exp["blocks"]
+        assert bz2.decompress(out) == data
+
+
+@pytest.mark.parametrize("idx", range(len(GOLDEN["large"])))
+def test_golden_large(orc, idx):
+    ent = GOLDEN["large"][idx]
+    data = corpus.segment(ent["kind"], ent["n"], ent["seed"])
+    assert hashlib.sha256(data.tobytes()).hexdigest() == ent["input_sha256"]
+    for level, exp in ent["streams"].items():
+        out, nb = orc.compress(data, int(level))
+        assert hashlib.sha256(out).hexdigest() == exp["sha256"]
+        assert len(out) == exp["len"] and nb == exp["blocks"]
+        assert bz2.decompress(out) == data.tobytes()
+
+
+def test_bzip2_cli_roundtrip(orc, tmp_path):
+    if not os.path.exists("/usr/bin/bzip2"):
+        pytest.skip("no bzip2 binary")
+    data = corpus.mixed(2, 123, seg_bytes=300000).tobytes()
+    out, _ = orc.compress(data, 3)
+    p = tmp_path / "x.bz2"
+    p.write_bytes(out)
+    got = subprocess.run(["/usr/bin/bzip2", "-dc", str(p)], capture_output=True, check=True).stdout
+    assert got == data
+
+
+def test_rle1_rule(orc):
+    # run-free data: each -9 block holds exactly bs-4 input bytes
+    d = corpus.text(2000000, 9)
+    starts = orc.split(d, 9)
+    assert list(starts) == [0, 899996, 1799992]
+    # RLE1 of a 255+4 run: 4 bytes + count 251, then 4 bytes + count 0
+    used, blk, pres, crc = orc.rle1_block(b"q" * 259 + b"r", 100000)
+    assert blk.tobytes() == b"qqqq" + bytes([251]) + b"qqqq" + bytes([0]) + b"r"
+    assert pres[ord("q")] and pres[251] and pres[0] and pres[ord("r")] and pres.sum() == 4
+    assert crc == _crc_bitwise(b"q" * 259 + b"r")
+    # a block never exceeds block_size bytes after RLE1
+    rng = np.random.default_rng(5)
+    d = corpus.segment("runs", 700000, 3)
+    pos = 0
+    while pos < d.size:
+        used, blk, pres, crc = orc.rle1_block(d[pos:], 100000)
+        assert 0 < blk.size <= 100000
+        pos += used
+
+
+def test_bwt_vs_bruteforce(orc):
+    rng = np.random.default_rng(11)
+    cases = [b"banana", b"abracadabra", b"mississippi", b"aaaaab", b"abcabcabd",
+             rng.integers(0, 3, 500, dtype=np.uint8).tobytes(),
+             rng.integers(0, 256, 2000, dtype=np.uint8).tobytes(),
+             corpus.text(3000, 4).tobytes()]
+    for c in cases:
+        bw, orig, per = orc.bwt(c)
+        bf, first, last = orc.bwt_bruteforce(c)
+        assert np.array_equal(bw, bf)
+        assert per == 1 and orig == first == last
+
+
+def test_bwt_periodic(orc):
+    for w, k in ((b"ab", 50), (b"abc", 7), (b"xyzzy", 4), (b"a", 9)):
+        c = w * k
+        bw, orig, per = orc.bwt(c)
+        bf, first, last = orc.bwt_bruteforce(c)
+        assert np.array_equal(bw, bf)
+        assert per == k
+        assert first <= orig <= last or per == len(c)
+
+
+def test_mtf_rle2_small(orc):
+    # BWT "aaab" with symbols {a, b}: positions 0,0,0,1 -> run of 3 zeros = RUNA RUNA(?)
+    pres = np.zeros(256, dtype=np.uint8)
+    pres[ord("a")] = pres[ord("b")] = 1
+    mtf, alpha, freq = orc.mtf_rle2(b"aaab", pres)
+    # run length 3 -> bijective base 2 digits of 3: (3-1)=2 -> RUNA, then (2-2)>>1=0 -> RUNA
+    assert list(mtf) == [0, 0, 2, 3]
+    assert alpha == 4 and freq[0] == 2 and freq[2] == 1 and freq[3] == 1
+
+
+def _huffman_cost(freqs):
+    h = [(f, i) for i, f in enumerate(freqs)]
+    heapq.heapify(h)
+    cost = 0
+    cnt = len(freqs)
+    while len(h) > 1:
+        a = heapq.heappop(h)
+        b = heapq.heappop(h)
+        cost += a[0] + b[0]
+        heapq.heappush(h, (a[0] + b[0], cnt))
+        cnt += 1
+    return cost
+
+
+def test_allocator_properties(orc):
+    rng = np.random.default_rng(17)
+    for trial in range(200):
+        n = int(rng.integers(3, 259))
+        kind = trial % 4
+        if kind == 0:
+            f = rng.integers(0, 1000, n)
+        elif kind == 1:
+            f = rng.integers(0, 3, n)
+        elif kind == 2:
+            fib = [1, 1]
+            while len(fib) < min(n, 28):
+                fib.append(fib[-1] + fib[-2])
+            f = np.array(fib[:n] + [0] * max(0, n - len(fib)), dtype=np.int64)  # forces the length limit
+        else:
+            f = np.zeros(n, dtype=np.int64)
+            f[rng.integers(0, n)] = 5
+        f = np.sort(f).astype(np.int32)
+        lens = orc.huffman_allocate(f, 20)
+        assert lens.min() >= 1 and lens.max() <= 20
+        if kind == 2 and n >= 28:
+            assert lens.max() == 20  # the relocation branch ran
+        assert sum(2.0 ** -int(l) for l in lens) == 1.0  # Kraft equality
+        assert all(lens[i] >= lens[i + 1] for i in range(n - 1))  # non-increasing
+        if lens.max() < 20 and f.min() > 0:
+            assert int((f.astype(np.int64) * lens).sum()) == _huffman_cost([int(x) for x in f])
+
+
+def test_huffman_stage_properties(orc):
+    d = corpus.text(120000, 21)
+    used, blk, pres, crc = orc.rle1_block(d, 900000)
+    bw, orig, per = orc.bwt(blk)
+    mtf, alpha, freq = orc.mtf_rle2(bw, pres)
+    assert freq.sum() == mtf.size and mtf[-1] == alpha - 1
+    nt, lens, sel, iters = orc.huffman_optimise(mtf, alpha, freq, want_iters=True)
+    assert nt == 6 and sel.size == (mtf.size + 49) // 50
+    assert np.array_equal(iters[3], lens)
+    for t in range(nt):
+        l = lens[t, :alpha]
+        assert l.min() >= 1 and l.max() <= 20
+        assert sum(2.0 ** -int(x) for x in l) == 1.0
+    # selectors re-derived naively against the pass-3 lengths
+    prev = iters[2]
+    for g in range(0, sel.size, 97):
+        grp = mtf[g * 50:(g + 1) * 50]
+        costs = [int(prev[t, grp].sum()) for t in range(nt)]
+        assert sel[g] == int(np.argmin(costs))
+    merged = orc.huffman_codes(nt, alpha, lens)
+    for t in range(nt):
+        codes = sorted((int(merged[t, j]) >> 24, int(merged[t, j]) & 0xFFFFFF) for j in range(alpha))
+        # canonical: prefix-free and increasing
+        strs = [format(c, "0%db" % l) for l, c in codes]
+        for a, b in zip(strs, strs[1:]):
+            assert not b.startswith(a)
+
+
+def test_mt_equals_st(orc):
+    d = corpus.mixed(3, 5, seg_bytes=400000)
+    a, na = orc.compress(d, 2, threads=1)
+    b, nb = orc.compress(d, 2, threads=4)
+    assert a == b and na == nb
