@@ -26,7 +26,7 @@ def shard_ranges(starts, n_total, world):
     for r in range(world):
         target = n_total * (r + 1) / world
         e = b
-        while e < nb and (r == world - 1 or edges[e + 1] <= target or e == b and False):
+        while e < nb and edges[e + 1] <= target:
             e += 1
         if r == world - 1:
             e = nb

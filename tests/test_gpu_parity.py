@@ -214,11 +214,15 @@ def test_sharded_engine_on_gpu(ctx, orc):
     d = corpus.mixed(5, 77, seg_bytes=500000)
     want, _ = orc.compress(d, 3)
     assert parallel.compress_sharded(d, 3, ctx) == want
-    segs = []
-    for r in range(3):
-        box = {}
-        parallel.compress_sharded(d, 3, ctx, rank=r, world=3,
-                                  gather=lambda s, box=box: box.setdefault("s", s) and None or [None] * 3)
-        segs.append(box["s"])
-    from bzip2_amd._lib import stitch
-    assert stitch(3, segs) == want
+    held = {}
+
+    def make_gather(r):
+        def gather(seg):
+            held[r] = seg
+            return [held[k] for k in range(3)] if r == 0 else None
+        return gather
+
+    out = None
+    for r in (2, 1, 0):  # rank 0 last, once every shard exists
+        out = parallel.compress_sharded(d, 3, ctx, rank=r, world=3, gather=make_gather(r))
+    assert out == want
