@@ -131,7 +131,7 @@ def main():
                                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                                "traffic": None, "avg_launch_ms": round(avg_ms, 4),
                                "launches": launches, "alg_bytes_per_launch": round(alg)}
-            bwt_cls = ["bwt_init", "radix_hist", "radix_scan", "radix_scatter", "bwt_keys",
+            bwt_cls = ["bwt_init", "radix_hist", "radix_scan", "radix_scatter", "bwt_keys", "bwt_ssort",
                        "bwt_rerank", "bwt_emit"]
             t_bwt = sum(prof[k]["ms"] for k in bwt_cls) * 1e-3 / args.steps
             n_rle = stats["rle_bytes"]

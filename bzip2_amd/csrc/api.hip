@@ -44,14 +44,15 @@ static void ensure_batch(bz2hip_ctx *c, int level, int nb_needed) {
     N.crc = dalloc<u32>(c, nb);
     N.keyA = dalloc<u64>(c, nb * S);
     N.keyB = dalloc<u64>(c, nb * S);
-    N.valA = dalloc<u32>(c, nb * S);
-    N.valB = dalloc<u32>(c, nb * S);
+    N.slA = dalloc<u64>(c, nb * S);
+    N.slB = dalloc<u64>(c, nb * S);
     N.rank = dalloc<u32>(c, nb * S);
-    N.grp = dalloc<u32>(c, nb * S);
-    N.sa = dalloc<u32>(c, nb * S);
+    N.mS = dalloc<u32>(c, nb); N.mL = dalloc<u32>(c, nb); N.mSn = dalloc<u32>(c, nb); N.mLn = dalloc<u32>(c, nb);
+    N.hcur = dalloc<u32>(c, nb); N.huse = dalloc<u32>(c, nb); N.state = dalloc<u32>(c, nb);
+    N.par = dalloc<u32>(c, nb); N.leftg = dalloc<u32>(c, nb);
     N.tilehist = dalloc<u32>(c, nb * N.TPB * 256);
     N.digitbase = dalloc<u32>(c, nb * 256);
-    N.tileagg = dalloc<u32>(c, nb * N.TPB);
+    N.tileagg = dalloc<u32>(c, nb * N.TPB * 4);
     N.nheads = dalloc<u32>(c, nb);
     N.active = dalloc<u32>(c, nb);
     N.rounds = dalloc<u32>(c, nb);
@@ -238,7 +239,7 @@ static size_t compress_core(bz2hip_ctx *c, const u8 *d_in, size_t n, int level, 
     size_t pos = 0;
     bool wrote_header = !header;
     c->st_blocks = c->st_rounds = c->st_rle_bytes = c->st_periodic = 0;
-    c->st_sorted_elems = c->st_nr = 0;
+    c->st_sorted_elems = c->st_nr = c->st_s_elems = 0;
     std::vector<u32> starts;
     bool any_frame = false;
     while (pos < n) {
@@ -543,6 +544,7 @@ extern "C" int bz2hip_bwt(bz2hip_ctx *c, const uint8_t *blocks, const uint32_t *
             int nb = (int)std::min<u32>((u32)B.NB, count - b0);
             HIPCHK(hipMemcpy2D(B.T, B.S, blocks + (size_t)b0 * stride, stride, maxn, nb, hipMemcpyHostToDevice));
             HIPCHK(hipMemcpy(B.n, n + b0, nb * sizeof(u32), hipMemcpyHostToDevice));
+            run_present(c, nb, maxn);
             run_bwt_n(c, nb, maxn);
             HIPCHK(hipStreamSynchronize(c->stream));
             if (maxn) HIPCHK(hipMemcpy2D(bwt + (size_t)b0 * stride, stride, B.bwt, B.S, maxn, nb, hipMemcpyDeviceToHost));
@@ -709,7 +711,7 @@ extern "C" int bz2hip_rle1_split(bz2hip_ctx *c, const uint8_t *in, size_t n, int
 // ------------------------------------------------------------------ profiling
 static const char *k_prof_names[P_COUNT] = {
     "rle1_scan", "rle1_split", "rle1_emit", "crc", "bwt_init", "radix_hist", "radix_scan",
-    "radix_scatter", "bwt_keys", "bwt_rerank", "bwt_emit", "mtf_state", "mtf_compose",
+    "radix_scatter", "bwt_keys", "bwt_ssort", "bwt_rerank", "bwt_emit", "mtf_state", "mtf_compose",
     "mtf_replay", "rle2", "huf_seed", "huf_select", "huf_lengths", "huf_codes", "huf_header",
     "pack", "frame"};
 

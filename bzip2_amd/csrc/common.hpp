@@ -115,6 +115,7 @@ enum ProfClass {
     P_RADIX_SCAN,
     P_RADIX_SCATTER,
     P_BWT_KEYS,
+    P_BWT_SSORT,
     P_BWT_RERANK,
     P_BWT_EMIT,
     P_MTF_STATE,

@@ -35,12 +35,14 @@ struct Batch {
     u32 *present = nullptr; // [NB][8] bitmap words (bit v of word v>>5)
     u32 *crc = nullptr;     // [NB]
     // BWT
-    u64 *keyA = nullptr, *keyB = nullptr;
-    u32 *valA = nullptr, *valB = nullptr;
-    u32 *rank = nullptr, *grp = nullptr, *sa = nullptr;
+    u64 *keyA = nullptr, *keyB = nullptr; // round-0 / L-list radix ping-pong (element words E)
+    u64 *slA = nullptr, *slB = nullptr;   // S-list ping-pong
+    u32 *rank = nullptr;
+    u32 *mS = nullptr, *mL = nullptr, *mSn = nullptr, *mLn = nullptr; // [NB] list lengths
+    u32 *hcur = nullptr, *huse = nullptr, *state = nullptr, *par = nullptr, *leftg = nullptr;
     u32 *tilehist = nullptr;  // [NB][TPB][256]
     u32 *digitbase = nullptr; // [NB][256]
-    u32 *tileagg = nullptr;   // [NB][TPB]
+    u32 *tileagg = nullptr;   // [NB][TPB][4]
     u32 *nheads = nullptr;    // [NB]
     u32 *active = nullptr;    // [NB]
     u32 *rounds = nullptr;    // [NB]
@@ -104,6 +106,7 @@ struct bz2hip_ctx {
     double prof_bytes[P_COUNT] = {0};
     // stats of the last call
     u64 st_blocks = 0, st_rounds = 0, st_rle_bytes = 0, st_periodic = 0;
+    u64 st_s_elems = 0;      // elements sorted by the LDS (S) path, summed over rounds
     u64 st_sorted_elems = 0; // sum over radix passes of elements moved
     u64 st_nr = 0;           // sum over blocks of n_b * doubling rounds_b
     // streaming state
@@ -165,6 +168,7 @@ struct ProfScope {
 
 // stage drivers (each in its own .hip file)
 void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn);                       // k2_bwt.hip
+void run_present(bz2hip_ctx *c, int nb, u32 maxn);                     // k2_bwt.hip
 void run_mtf(bz2hip_ctx *c, int nb, u32 maxn);                         // k3_mtf.hip
 void run_huffman(bz2hip_ctx *c, int nb, u32 maxmtf);                   // k4_huffman.hip
 // writes blocks at absolute bit offsets into d_out (zeroed); first_bit = bit offset of block 0

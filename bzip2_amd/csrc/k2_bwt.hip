@@ -4,55 +4,133 @@
 // constructBWT :3369-3481).  The BWT string of a block is unique, so any correct rotation sort
 // reproduces it; `orig` is unique unless the block is a perfect power w^k.
 //
-// Algorithm (all blocks of the batch in every launch, grid.y = block):
-//   round 0 : key64 = first 8 bytes of each rotation (cyclic), 8 LSD passes of 8 bits
-//   round r : key40 = (rank(i) << 20) | rank((i+h) mod n), 5 LSD passes, h = 8,16,32,...
-//   after every sort: head flags -> rank = position of the group's head (max-scan)
-//   a block stops when every group is a singleton, or when h >= n (then it is periodic).
-// Each LSD pass = tile digit histogram (LDS atomics) -> per-block scan -> stable scatter
-// (wave64 ballot matching, per-wave LDS counters).  HBM-bound; no MFMA.
+// Element word E (u64):  [59:40] grp = SA position of the element's group head
+//                        [39:20] k2  = rank((i + h) mod n), filled in per round
+//                        [19: 0] i   = rotation start
+// Round 0: the first d0 symbols of every rotation (dense symbol codes, bps bits each, d0*bps <= 40)
+//   are packed into bits [59:20]; 5 LSD radix passes of 8 bits over those 40 bits; ranks by head
+//   flags.  Sorted depth h = d0.
+// Round r: only rotations in groups of size > 1 are still listed.  Groups of <= GS elements that
+//   lie inside one tile live in the S-list and are sorted by one workgroup in LDS (bitonic on E);
+//   the others live in the L-list and take 5 global LSD passes.  After sorting, head flags split
+//   the groups, ranks are refreshed, singletons write their BWT byte and leave, h doubles.
+// A block ends when both lists are empty, or when h >= n (periodic block: the leftovers are the
+// k-fold ties; they are flushed in list order).
+// LSD pass = tile digit histogram (LDS atomics) -> per-block scan -> stable scatter (wave64
+// ballot matching, per-wave LDS counters).  HBM-bound; no MFMA.
 #include "ctx.hpp"
+#include <climits>
+
+#define GS 1024          // largest group the S-path takes
+#define SC 3072          // S-tile nominal stride (window = SC + GS = 4096)
+#define KEY_SHIFT 20
+#define E_IMASK 0xFFFFFull
+
+enum { ST_DONE = 0, ST_ACTIVE = 1, ST_FIN = 2 };
+enum { MODE_NORMAL = 0, MODE_ROUND0 = 1, MODE_FINAL = 2 };
+enum { CLS_NONE = 0, CLS_SINGLE = 1, CLS_SMALL = 2, CLS_LKEEP = 3 };
+#define CROSS INT_MAX
+#define NOHEAD (INT_MIN / 2)
+
+// ------------------------------------------------------------------ per-block control
+__global__ void k2_reset(const u32 *__restrict__ nArr, const u32 *__restrict__ present,
+                         u32 *mS, u32 *mL, u32 *mSn, u32 *mLn, u32 *hcur, u32 *huse, u32 *state,
+                         u32 *par, u32 *rounds, u32 *leftg, u32 *periodic, u32 *ctl, u32 nb) {
+    u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    u32 uniq = 0;
+    for (int q = 0; q < 8; q++) uniq += __popc(present[b * 8 + q]);
+    u32 bps = 1;
+    while ((1u << bps) < uniq) bps++;
+    u32 d0 = 40 / bps;
+    mS[b] = 0; mL[b] = 0; mSn[b] = 0; mLn[b] = 0;
+    hcur[b] = d0; huse[b] = d0;
+    state[b] = nArr[b] > 0 ? ST_ACTIVE : ST_DONE;
+    par[b] = 0; rounds[b] = 0; leftg[b] = 0; periodic[b] = 1;
+    atomicAdd(&ctl[8], nArr[b]);
+}
+
+// after every round: move the "next" counters in, decide who continues
+__global__ void k2_ctl(const u32 *__restrict__ nArr, u32 *mS, u32 *mL, u32 *mSn, u32 *mLn,
+                       u32 *hcur, u32 *huse, u32 *state, u32 *par, u32 *rounds, u32 *ctl, u32 nb) {
+    u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    if (state[b] != ST_ACTIVE) return;
+    u32 s = mSn[b], l = mLn[b];
+    mS[b] = s; mL[b] = l; mSn[b] = 0; mLn[b] = 0;
+    par[b] ^= 1u; // survivors were written to the other S buffer
+    u32 n = nArr[b], h = hcur[b];
+    if (s + l == 0) {
+        state[b] = ST_DONE;
+    } else if (h >= n) {
+        state[b] = ST_FIN;
+        atomicOr(&ctl[4], 1u);
+        atomicMax(&ctl[5], s);
+        atomicMax(&ctl[6], l);
+    } else {
+        huse[b] = h;
+        hcur[b] = (h > (1u << 30)) ? h : 2 * h;
+        rounds[b] += 1;
+        atomicOr(&ctl[0], 1u);
+        atomicMax(&ctl[1], s);
+        atomicMax(&ctl[2], l);
+        atomicAdd(&ctl[3], l);
+        atomicAdd(&ctl[7], s);
+    }
+}
 
 // ------------------------------------------------------------------ round 0 keys
 __global__ __launch_bounds__(RT_THREADS) void k2_init_keys(const u8 *__restrict__ T,
                                                            const u32 *__restrict__ nArr,
-                                                           u64 *__restrict__ key,
-                                                           u32 *__restrict__ val, u32 S) {
+                                                           const u32 *__restrict__ present,
+                                                           u64 *__restrict__ key, u32 S) {
     const u32 b = blockIdx.y;
     const u32 n = nArr[b];
     const u32 base = blockIdx.x * RTILE;
+    __shared__ u8 smap[256];
+    __shared__ u32 s_bps;
+    if (threadIdx.x < 256) {
+        u32 v = threadIdx.x;
+        const u32 *pw = present + b * 8;
+        u32 cnt = 0;
+        for (u32 wi = 0; wi < (v >> 5); wi++) cnt += __popc(pw[wi]);
+        cnt += __popc(pw[v >> 5] & ((1u << (v & 31)) - 1u));
+        smap[v] = (u8)cnt;
+        if (v == 255) {
+            u32 uniq = cnt + ((pw[7] >> 31) & 1u);
+            u32 bps = 1;
+            while ((1u << bps) < uniq) bps++;
+            s_bps = bps;
+        }
+    }
+    __syncthreads();
     if (base >= n) return;
+    const u32 bps = s_bps;
+    const u32 d0 = 40 / bps;
     const u8 *t = T + (size_t)b * S;
-#pragma unroll 4
     for (int k = 0; k < RT_ITEMS; k++) {
         u32 i = base + k * RT_THREADS + threadIdx.x;
         if (i >= n) break;
         u64 kk = 0;
-        if (i + 8 <= n) {
-#pragma unroll
-            for (int q = 0; q < 8; q++) kk = (kk << 8) | t[i + q];
-        } else {
-            u32 p = i;
-            for (int q = 0; q < 8; q++) {
-                kk = (kk << 8) | t[p];
-                p++;
-                if (p >= n) p = 0;
-            }
+        u32 p = i;
+        for (u32 q = 0; q < d0; q++) {
+            kk = (kk << bps) | smap[t[p]];
+            p++;
+            if (p >= n) p = 0;
         }
-        key[(size_t)b * S + i] = kk;
-        val[(size_t)b * S + i] = i;
+        key[(size_t)b * S + i] = (kk << KEY_SHIFT) | (u64)i;
     }
 }
 
-// ------------------------------------------------------------------ LSD radix pass
+// ------------------------------------------------------------------ LSD radix pass (u64 words)
 __global__ __launch_bounds__(RT_THREADS) void k2_radix_hist(const u64 *__restrict__ key,
-                                                            const u32 *__restrict__ nArr,
-                                                            const u32 *__restrict__ active,
+                                                            const u32 *__restrict__ cntArr,
+                                                            const u32 *__restrict__ state,
                                                             u32 *__restrict__ tilehist, u32 S,
                                                             u32 TPB, int shift) {
     const u32 b = blockIdx.y;
-    if (!active[b]) return;
-    const u32 n = nArr[b];
+    if (state[b] != ST_ACTIVE) return;
+    const u32 n = cntArr[b];
     const u32 base = blockIdx.x * RTILE;
     if (base >= n) return;
     __shared__ u32 hist[256];
@@ -68,14 +146,13 @@ __global__ __launch_bounds__(RT_THREADS) void k2_radix_hist(const u64 *__restric
     tilehist[((size_t)b * TPB + blockIdx.x) * 256 + threadIdx.x] = hist[threadIdx.x];
 }
 
-// one workgroup per block: exclusive scan of tile counts per digit, then digit bases
-__global__ __launch_bounds__(256) void k2_radix_scan(const u32 *__restrict__ nArr,
-                                                     const u32 *__restrict__ active,
+__global__ __launch_bounds__(256) void k2_radix_scan(const u32 *__restrict__ cntArr,
+                                                     const u32 *__restrict__ state,
                                                      u32 *__restrict__ tilehist,
                                                      u32 *__restrict__ digitbase, u32 TPB) {
     const u32 b = blockIdx.x;
-    if (!active[b]) return;
-    const u32 n = nArr[b];
+    if (state[b] != ST_ACTIVE) return;
+    const u32 n = cntArr[b];
     const u32 tiles = (n + RTILE - 1) / RTILE;
     __shared__ u32 sm[8];
     u32 *th = tilehist + (size_t)b * TPB * 256 + threadIdx.x;
@@ -102,13 +179,12 @@ __device__ __forceinline__ u64 match8(u32 d, bool valid) {
 }
 
 __global__ __launch_bounds__(RT_THREADS) void k2_radix_scatter(
-    const u64 *__restrict__ keyIn, const u32 *__restrict__ valIn, u64 *__restrict__ keyOut,
-    u32 *__restrict__ valOut, const u32 *__restrict__ nArr, const u32 *__restrict__ active,
-    const u32 *__restrict__ tilehist, const u32 *__restrict__ digitbase, u32 S, u32 TPB,
-    int shift) {
+    const u64 *__restrict__ keyIn, u64 *__restrict__ keyOut, const u32 *__restrict__ cntArr,
+    const u32 *__restrict__ state, const u32 *__restrict__ tilehist,
+    const u32 *__restrict__ digitbase, u32 S, u32 TPB, int shift) {
     const u32 b = blockIdx.y;
-    if (!active[b]) return;
-    const u32 n = nArr[b];
+    if (state[b] != ST_ACTIVE) return;
+    const u32 n = cntArr[b];
     const u32 base = blockIdx.x * RTILE;
     if (base >= n) return;
     __shared__ u32 whist[4][256];
@@ -117,9 +193,7 @@ __global__ __launch_bounds__(RT_THREADS) void k2_radix_scatter(
     for (int q = threadIdx.x; q < 4 * 256; q += RT_THREADS) (&whist[0][0])[q] = 0;
     __syncthreads();
     const u64 *kp = keyIn + (size_t)b * S;
-    const u32 *vp = valIn + (size_t)b * S;
     u64 keys[RT_ITEMS];
-    u32 vals[RT_ITEMS];
     u32 lr[RT_ITEMS];
     const u64 lt = (1ull << lane) - 1ull;
 #pragma unroll
@@ -127,9 +201,7 @@ __global__ __launch_bounds__(RT_THREADS) void k2_radix_scatter(
         u32 i = base + w * (RTILE / 4) + k * 64 + lane;
         bool valid = i < n;
         u64 kk = valid ? kp[i] : 0;
-        u32 vv = valid ? vp[i] : 0;
         keys[k] = kk;
-        vals[k] = vv;
         u32 d = (u32)(kk >> shift) & 255u;
         u64 m = match8(d, valid);
         u32 r = __popcll(m & lt);
@@ -145,7 +217,6 @@ __global__ __launch_bounds__(RT_THREADS) void k2_radix_scatter(
     }
     __syncthreads();
     {
-        // exclusive prefix over waves per digit + global offset of this tile's digit run
         const u32 d = threadIdx.x;
         u32 run = 0;
 #pragma unroll
@@ -158,320 +229,600 @@ __global__ __launch_bounds__(RT_THREADS) void k2_radix_scatter(
     }
     __syncthreads();
     u64 *ko = keyOut + (size_t)b * S;
-    u32 *vo = valOut + (size_t)b * S;
 #pragma unroll
     for (int k = 0; k < RT_ITEMS; k++) {
         u32 i = base + w * (RTILE / 4) + k * 64 + lane;
         if (i < n) {
             u32 d = (u32)(keys[k] >> shift) & 255u;
-            u32 dst = gofs[d] + whist[w][d] + lr[k];
-            ko[dst] = keys[k];
-            vo[dst] = vals[k];
+            ko[gofs[d] + whist[w][d] + lr[k]] = keys[k];
         }
-    }
-}
-
-// ------------------------------------------------------------------ re-rank
-// head(j) = j == 0 || key[j] != key[j-1];  grp[j] = position of nearest head <= j.
-// phase 1: per tile, last head position + 1 (0 = none) and head count.
-__global__ __launch_bounds__(RT_THREADS) void k2_rerank_p1(const u64 *__restrict__ key,
-                                                           const u32 *__restrict__ nArr,
-                                                           const u32 *__restrict__ active,
-                                                           u32 *__restrict__ tileagg,
-                                                           u32 *__restrict__ nheads, u32 S,
-                                                           u32 TPB) {
-    const u32 b = blockIdx.y;
-    if (!active[b]) return;
-    const u32 n = nArr[b];
-    const u32 base = blockIdx.x * RTILE;
-    if (base >= n) return;
-    __shared__ u32 sm[8];
-    const u64 *kp = key + (size_t)b * S;
-    u32 last = 0, cnt = 0;
-#pragma unroll 4
-    for (int k = 0; k < RT_ITEMS; k++) {
-        u32 j = base + k * RT_THREADS + threadIdx.x;
-        if (j < n) {
-            bool head = (j == 0) || (kp[j] != kp[j - 1]);
-            if (head) {
-                last = j + 1;
-                cnt++;
-            }
-        }
-    }
-    u32 tl = block_reduce_max<RT_THREADS>(last, sm);
-    u32 tc = block_reduce_add<RT_THREADS>(cnt, sm);
-    if (threadIdx.x == 0) {
-        tileagg[(size_t)b * TPB + blockIdx.x] = tl;
-        atomicAdd(&nheads[b], tc);
-    }
-}
-
-// phase 2: exclusive max-scan of tile aggregates (one workgroup per block)
-__global__ __launch_bounds__(256) void k2_rerank_p2(const u32 *__restrict__ nArr,
-                                                    const u32 *__restrict__ active,
-                                                    u32 *__restrict__ tileagg, u32 TPB) {
-    const u32 b = blockIdx.x;
-    if (!active[b]) return;
-    const u32 tiles = (nArr[b] + RTILE - 1) / RTILE;
-    __shared__ u32 sm[8];
-    u32 carry = 0;
-    for (u32 t0 = 0; t0 < tiles; t0 += 256) {
-        u32 t = t0 + threadIdx.x;
-        u32 v = (t < tiles) ? tileagg[(size_t)b * TPB + t] : 0;
-        u32 tot;
-        u32 inc = block_incl_scan_max<256>(v, sm, &tot);
-        // exclusive = max over previous elements
-        u32 prev = __shfl_up(inc, 1, 64);
-        u32 ex;
-        if (lane_id() == 0) {
-            // previous wave's inclusive total
-            ex = 0;
-            for (int q = 0; q < wave_id(); q++) ex = max(ex, sm[q]);
-        } else {
-            ex = prev;
-        }
-        ex = max(ex, carry);
-        if (t < tiles) tileagg[(size_t)b * TPB + t] = ex;
-        carry = max(carry, tot);
-        __syncthreads();
-    }
-}
-
-// phase 3: grp[j], rank[sa[j]] = grp[j], sa[j] = val[j]
-__global__ __launch_bounds__(RT_THREADS) void k2_rerank_p3(
-    const u64 *__restrict__ key, const u32 *__restrict__ val, const u32 *__restrict__ nArr,
-    const u32 *__restrict__ active, const u32 *__restrict__ tileagg, u32 *__restrict__ grp,
-    u32 *__restrict__ rank, u32 *__restrict__ sa, u32 S, u32 TPB) {
-    const u32 b = blockIdx.y;
-    if (!active[b]) return;
-    const u32 n = nArr[b];
-    const u32 base = blockIdx.x * RTILE;
-    if (base >= n) return;
-    __shared__ u32 wlast[4];
-    const int w = wave_id(), lane = lane_id();
-    const u64 *kp = key + (size_t)b * S;
-    const u32 *vp = val + (size_t)b * S;
-    u64 hm[RT_ITEMS];
-    u32 myv[RT_ITEMS];
-    u32 last = 0; // last head (+1) seen by this wave
-#pragma unroll
-    for (int k = 0; k < RT_ITEMS; k++) {
-        u32 j = base + w * (RTILE / 4) + k * 64 + lane;
-        bool head = false;
-        u32 v = 0;
-        if (j < n) {
-            head = (j == 0) || (kp[j] != kp[j - 1]);
-            v = vp[j];
-        }
-        myv[k] = v;
-        u64 m = __ballot(head);
-        hm[k] = m;
-        if (m) last = base + w * (RTILE / 4) + k * 64 + (63 - __clzll((unsigned long long)m)) + 1;
-    }
-    if (lane == 0) wlast[w] = last;
-    __syncthreads();
-    u32 carry = tileagg[(size_t)b * TPB + blockIdx.x];
-    for (int q = 0; q < w; q++) carry = max(carry, wlast[q]);
-    const u64 le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
-#pragma unroll
-    for (int k = 0; k < RT_ITEMS; k++) {
-        u32 rowbase = base + w * (RTILE / 4) + k * 64;
-        u32 j = rowbase + lane;
-        u64 m = hm[k] & le;
-        u32 g = m ? (rowbase + (63 - __clzll((unsigned long long)m)) + 1) : carry;
-        if (hm[k]) carry = rowbase + (63 - __clzll((unsigned long long)hm[k])) + 1;
-        if (j < n) {
-            u32 gg = g - 1;
-            grp[(size_t)b * S + j] = gg;
-            sa[(size_t)b * S + j] = myv[k];
-            rank[(size_t)b * S + myv[k]] = gg;
-        }
-    }
-}
-
-// per-round control: decide which blocks continue; one thread per block
-__global__ void k2_round_ctl(const u32 *__restrict__ nArr, u32 *__restrict__ nheads,
-                             u32 *__restrict__ active, u32 *__restrict__ rounds,
-                             u32 *__restrict__ periodic, u32 *__restrict__ ctl, u32 nb,
-                             u32 h_next) {
-    u32 b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb) return;
-    if (!active[b]) return;
-    u32 n = nArr[b], heads = nheads[b];
-    bool cont = (heads < n) && (h_next < n);
-    if (cont) {
-        rounds[b] += 1;
-        nheads[b] = 0;
-        atomicOr(&ctl[0], 1u);
-        atomicAdd(&ctl[1], n); // elements sorted in the coming round (for the roofline figure)
-    } else {
-        active[b] = 0;
-        periodic[b] = (heads < n) ? (n / heads) : 1;
     }
 }
 
 // ------------------------------------------------------------------ doubling keys
-__global__ __launch_bounds__(RT_THREADS) void k2_build_keys(
-    const u32 *__restrict__ sa, const u32 *__restrict__ grp, const u32 *__restrict__ rank,
-    const u32 *__restrict__ nArr, const u32 *__restrict__ active, u64 *__restrict__ key,
-    u32 *__restrict__ val, u32 S, u32 h) {
+// z = 0: S-list, z = 1: L-list.  E |= rank((i + h) mod n) << 20
+__global__ __launch_bounds__(RT_THREADS) void k2_keys(u64 *__restrict__ slA, u64 *__restrict__ slB,
+                                                      u64 *__restrict__ keyA,
+                                                      const u32 *__restrict__ par,
+                                                      const u32 *__restrict__ mS,
+                                                      const u32 *__restrict__ mL,
+                                                      const u32 *__restrict__ state,
+                                                      const u32 *__restrict__ huse,
+                                                      const u32 *__restrict__ nArr,
+                                                      const u32 *__restrict__ rank, u32 S) {
     const u32 b = blockIdx.y;
-    if (!active[b]) return;
-    const u32 n = nArr[b];
+    if (state[b] != ST_ACTIVE) return;
+    const u32 m = blockIdx.z ? mL[b] : mS[b];
     const u32 base = blockIdx.x * RTILE;
-    if (base >= n) return;
-    const size_t o = (size_t)b * S;
+    if (base >= m) return;
+    u64 *list = (blockIdx.z ? keyA : (par[b] ? slB : slA)) + (size_t)b * S;
+    const u32 n = nArr[b], h = huse[b];
+    const u32 *rk = rank + (size_t)b * S;
 #pragma unroll 4
     for (int k = 0; k < RT_ITEMS; k++) {
         u32 j = base + k * RT_THREADS + threadIdx.x;
-        if (j < n) {
-            u32 i = sa[o + j];
+        if (j < m) {
+            u64 e = list[j];
+            u32 i = (u32)(e & E_IMASK);
             u32 i2 = i + h;
             if (i2 >= n) i2 -= n;
-            key[o + j] = ((u64)grp[o + j] << 20) | (u64)rank[o + i2];
-            val[o + j] = i;
+            list[j] = e | ((u64)rk[i2] << KEY_SHIFT);
         }
     }
 }
 
-// ------------------------------------------------------------------ output
-__global__ __launch_bounds__(RT_THREADS) void k2_emit_bwt(
-    const u8 *__restrict__ T, const u32 *__restrict__ sa, const u32 *__restrict__ rank,
-    const u32 *__restrict__ nArr, const u32 *__restrict__ periodic, u8 *__restrict__ bwt,
-    u32 *__restrict__ orig, u32 S, int tie_rule) {
+// ------------------------------------------------------------------ tile classification
+// buf[0..cnt) holds a run of the (sorted) list in LDS; wave-row layout: wave w owns
+// [w*1024, w*1024+1024), 16 rows of 64.  Computes for every element the slot of its old / new
+// group head (tile-local, may be negative = before the tile) and of the next new head.
+template <int MODE>
+__device__ __forceinline__ void tile_classify(const u64 *buf, int cnt, u64 prevE, bool has_prev,
+                                              int carryOld, int carryNew, bool end_head,
+                                              int *sm /* 12 ints */, int (&cls)[16],
+                                              u32 (&ngrp)[16], u32 (&spos)[16], int &nheads) {
+    const int w = wave_id(), lane = lane_id();
+    u64 nm[16], om[16];
+    int lastOld = NOHEAD, lastNew = NOHEAD, firstNew = CROSS;
+    int heads = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int rb = w * 1024 + k * 64;
+        const int idx = rb + lane;
+        bool nh = false, oh = false;
+        if (idx < cnt) {
+            u64 e = buf[idx];
+            if (idx == 0) {
+                if (!has_prev) {
+                    nh = true;
+                    oh = true;
+                } else {
+                    nh = (e >> KEY_SHIFT) != (prevE >> KEY_SHIFT);
+                    oh = (MODE == MODE_ROUND0) ? false : ((e >> 40) != (prevE >> 40));
+                }
+            } else {
+                u64 ep = buf[idx - 1];
+                nh = (e >> KEY_SHIFT) != (ep >> KEY_SHIFT);
+                oh = (MODE == MODE_ROUND0) ? false : ((e >> 40) != (ep >> 40));
+            }
+        }
+        u64 a = __ballot(nh), o = __ballot(oh);
+        nm[k] = a;
+        om[k] = o;
+        if (o) lastOld = rb + 63 - __clzll((unsigned long long)o);
+        if (a) {
+            lastNew = rb + 63 - __clzll((unsigned long long)a);
+            if (firstNew == CROSS) firstNew = rb + __ffsll((unsigned long long)a) - 1;
+            heads += __popcll(a);
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        sm[w] = lastOld;
+        sm[4 + w] = lastNew;
+        sm[8 + w] = firstNew;
+        sm[12 + w] = heads;
+    }
+    __syncthreads();
+    int cO = carryOld, cN = carryNew;
+    for (int q = 0; q < w; q++) {
+        if (sm[q] != NOHEAD) cO = sm[q];
+        if (sm[4 + q] != NOHEAD) cN = sm[4 + q];
+    }
+    int nx = end_head ? cnt : CROSS;
+    for (int q = 3; q > w; q--)
+        if (sm[8 + q] != CROSS) nx = sm[8 + q];
+    nheads = sm[12] + sm[13] + sm[14] + sm[15];
+    int ohi[16], nhi[16];
+    const u64 le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int rb = w * 1024 + k * 64;
+        u64 mo = om[k] & le, mn = nm[k] & le;
+        ohi[k] = mo ? rb + 63 - __clzll((unsigned long long)mo) : cO;
+        nhi[k] = mn ? rb + 63 - __clzll((unsigned long long)mn) : cN;
+        if (om[k]) cO = rb + 63 - __clzll((unsigned long long)om[k]);
+        if (nm[k]) cN = rb + 63 - __clzll((unsigned long long)nm[k]);
+    }
+    const u64 gt = (lane == 63) ? 0ull : (~0ull << (lane + 1));
+#pragma unroll
+    for (int k = 15; k >= 0; k--) {
+        const int rb = w * 1024 + k * 64;
+        const int idx = rb + lane;
+        u64 mn = nm[k] & gt;
+        int next = mn ? rb + __ffsll((unsigned long long)mn) - 1 : nx;
+        if (nm[k]) nx = rb + __ffsll((unsigned long long)nm[k]) - 1;
+        int c = CLS_NONE;
+        u32 g = 0, sp = 0;
+        if (idx < cnt) {
+            u64 e = buf[idx];
+            u32 gb = (MODE == MODE_ROUND0) ? 0u : (u32)(e >> 40);
+            g = gb + (u32)(nhi[k] - ohi[k]);
+            sp = gb + (u32)(idx - ohi[k]);
+            if (nhi[k] < 0 || next == CROSS) {
+                c = CLS_LKEEP;
+            } else {
+                int size = next - nhi[k];
+                c = (size == 1) ? CLS_SINGLE : (size <= GS ? CLS_SMALL : CLS_LKEEP);
+            }
+        }
+        cls[k] = c;
+        ngrp[k] = g;
+        spos[k] = sp;
+    }
+}
+
+// shared output stage: ranks, BWT bytes of finished rotations, survivors to the S / L lists
+template <int MODE>
+__device__ __forceinline__ void tile_emit(const u64 *buf, int cnt, const int (&cls)[16],
+                                          const u32 (&ngrp)[16], const u32 (&spos)[16],
+                                          u32 *__restrict__ rank, const u8 *__restrict__ T,
+                                          u8 *__restrict__ bwt, u32 n, u64 *__restrict__ sOut,
+                                          u32 *mSn_b, u64 *__restrict__ lOut, u32 lBase,
+                                          int *sm /* 12 ints */) {
+    const int w = wave_id(), lane = lane_id();
+    // counts of SMALL and LKEEP per wave
+    u32 cs = 0, cl = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        cs += (cls[k] == CLS_SMALL);
+        cl += (cls[k] == CLS_LKEEP);
+    }
+    if (MODE != MODE_FINAL) {
+        cs = wave_reduce_add(cs);
+        cl = wave_reduce_add(cl);
+        __syncthreads();
+        if (lane == 0) {
+            sm[w] = (int)cs;
+            sm[4 + w] = (int)cl;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            u32 tot = (u32)(sm[0] + sm[1] + sm[2] + sm[3]);
+            sm[8] = tot ? (int)atomicAdd(mSn_b, tot) : 0;
+        }
+        __syncthreads();
+    }
+    u32 sRun = 0, lRun = 0;
+    if (MODE != MODE_FINAL) {
+        sRun = (u32)sm[8];
+        lRun = lBase;
+        for (int q = 0; q < w; q++) {
+            sRun += (u32)sm[q];
+            lRun += (u32)sm[4 + q];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int idx = w * 1024 + k * 64 + lane;
+        const int c = cls[k];
+        u32 i = 0;
+        if (c != CLS_NONE) {
+            i = (u32)(buf[idx] & E_IMASK);
+            if (MODE != MODE_FINAL) rank[i] = ngrp[k];
+            if (MODE == MODE_FINAL || c == CLS_SINGLE) bwt[spos[k]] = T[i == 0 ? n - 1 : i - 1];
+        }
+        if (MODE != MODE_FINAL) {
+            u64 ms = __ballot(c == CLS_SMALL), ml = __ballot(c == CLS_LKEEP);
+            const u64 lt = (1ull << lane) - 1ull;
+            if (c == CLS_SMALL) sOut[sRun + __popcll(ms & lt)] = ((u64)ngrp[k] << 40) | i;
+            if (c == CLS_LKEEP) lOut[lRun + __popcll(ml & lt)] = ((u64)ngrp[k] << 40) | i;
+            sRun += __popcll(ms);
+            lRun += __popcll(ml);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ L-path re-rank
+// phase 1: per tile {last old head + 1, last new head + 1, LKEEP count}
+template <int MODE>
+__global__ __launch_bounds__(RT_THREADS) void k2_lrerank_p1(const u64 *__restrict__ key,
+                                                            const u32 *__restrict__ cntArr,
+                                                            const u32 *__restrict__ state, u32 want,
+                                                            u32 *__restrict__ tileagg, u32 S, u32 TPB) {
+    const u32 b = blockIdx.y;
+    if (state[b] != want) return;
+    const u32 m = cntArr[b];
+    const u32 base = blockIdx.x * RTILE;
+    if (base >= m) return;
+    __shared__ u64 buf[RTILE];
+    __shared__ int sm[16];
+    const u64 *kp = key + (size_t)b * S;
+    const int cnt = (int)min((u32)RTILE, m - base);
+    for (int q = threadIdx.x; q < RTILE; q += RT_THREADS) buf[q] = (q < cnt) ? kp[base + q] : ~0ull;
+    const bool has_prev = base > 0;
+    const u64 prevE = has_prev ? kp[base - 1] : 0;
+    bool end_head = true;
+    if (base + cnt < m) end_head = (kp[base + cnt] >> KEY_SHIFT) != (kp[base + cnt - 1] >> KEY_SHIFT);
+    __syncthreads();
+    int cls[16];
+    u32 ngrp[16], spos[16];
+    int nheads;
+    // carries are irrelevant for the aggregates: use NOHEAD so that heads before the tile read < 0
+    tile_classify<MODE>(buf, cnt, prevE, has_prev, NOHEAD, NOHEAD, end_head, sm, cls, ngrp, spos, nheads);
+    // aggregates
+    const int w = wave_id(), lane = lane_id();
+    int lastOld = 0, lastNew = 0;
+    u32 keep = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int idx = w * 1024 + k * 64 + lane;
+        if (idx < cnt) {
+            u64 e = buf[idx];
+            u64 ep = (idx == 0) ? prevE : buf[idx - 1];
+            bool first = (idx == 0 && !has_prev);
+            bool nh = first || (e >> KEY_SHIFT) != (ep >> KEY_SHIFT);
+            bool oh = (MODE == MODE_ROUND0) ? first : (first || (e >> 40) != (ep >> 40));
+            if (nh) lastNew = (int)base + idx + 1;
+            if (oh) lastOld = (int)base + idx + 1;
+        }
+        keep += (cls[k] == CLS_LKEEP);
+    }
+    __shared__ u32 red[8];
+    u32 tO = block_reduce_max<RT_THREADS>((u32)lastOld, red);
+    u32 tN = block_reduce_max<RT_THREADS>((u32)lastNew, red);
+    u32 tK = block_reduce_add<RT_THREADS>(keep, red);
+    if (threadIdx.x == 0) {
+        u32 *o = tileagg + ((size_t)b * TPB + blockIdx.x) * 4;
+        o[0] = tO; o[1] = tN; o[2] = tK; o[3] = (u32)nheads;
+    }
+}
+
+// phase 2: per block exclusive scans over tiles (max, max, add); mLn = total keep
+__global__ __launch_bounds__(256) void k2_lrerank_p2(const u32 *__restrict__ cntArr,
+                                                     const u32 *__restrict__ state, u32 want,
+                                                     u32 *__restrict__ tileagg, u32 *__restrict__ mLn,
+                                                     u32 *__restrict__ leftg, int final_mode, u32 TPB) {
+    const u32 b = blockIdx.x;
+    if (state[b] != want) return;
+    const u32 tiles = (cntArr[b] + RTILE - 1) / RTILE;
+    __shared__ u32 sm[8];
+    u32 cO = 0, cN = 0, cK = 0, cH = 0;
+    for (u32 t0 = 0; t0 < tiles; t0 += 256) {
+        u32 t = t0 + threadIdx.x;
+        u32 *a = tileagg + ((size_t)b * TPB + t) * 4;
+        u32 vO = 0, vN = 0, vK = 0, vH = 0;
+        if (t < tiles) { vO = a[0]; vN = a[1]; vK = a[2]; vH = a[3]; }
+        u32 totO, totN, totK, totH;
+        u32 iO = block_incl_scan_max<256>(vO, sm, &totO);
+        u32 eO = __shfl_up(iO, 1, 64);
+        if (lane_id() == 0) { eO = 0; for (int q = 0; q < wave_id(); q++) eO = max(eO, sm[q]); }
+        __syncthreads();
+        u32 iN = block_incl_scan_max<256>(vN, sm, &totN);
+        u32 eN = __shfl_up(iN, 1, 64);
+        if (lane_id() == 0) { eN = 0; for (int q = 0; q < wave_id(); q++) eN = max(eN, sm[q]); }
+        __syncthreads();
+        u32 eK = block_excl_scan_add<256>(vK, sm, &totK);
+        __syncthreads();
+        u32 eH = block_excl_scan_add<256>(vH, sm, &totH);
+        (void)eH;
+        if (t < tiles) { a[0] = max(eO, cO); a[1] = max(eN, cN); a[2] = cK + eK; }
+        cO = max(cO, totO); cN = max(cN, totN); cK += totK; cH += totH;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (final_mode) atomicAdd(&leftg[b], cH);
+        else mLn[b] = cK;
+    }
+}
+
+// phase 3
+template <int MODE>
+__global__ __launch_bounds__(RT_THREADS) void k2_lrerank_p3(
+    const u64 *__restrict__ key, u64 *__restrict__ lOutAll, u64 *slA, u64 *slB,
+    const u32 *__restrict__ par, const u32 *__restrict__ cntArr,
+    const u32 *__restrict__ state, u32 want, const u32 *__restrict__ tileagg,
+    u32 *__restrict__ rank, const u8 *__restrict__ T, u8 *__restrict__ bwt,
+    const u32 *__restrict__ nArr, u32 *__restrict__ mSn, u32 S, u32 TPB) {
+    const u32 b = blockIdx.y;
+    if (state[b] != want) return;
+    const u32 m = cntArr[b];
+    const u32 base = blockIdx.x * RTILE;
+    if (base >= m) return;
+    __shared__ u64 buf[RTILE];
+    __shared__ int sm[16];
+    const u64 *kp = key + (size_t)b * S;
+    const int cnt = (int)min((u32)RTILE, m - base);
+    for (int q = threadIdx.x; q < RTILE; q += RT_THREADS) buf[q] = (q < cnt) ? kp[base + q] : ~0ull;
+    const bool has_prev = base > 0;
+    const u64 prevE = has_prev ? kp[base - 1] : 0;
+    bool end_head = true;
+    if (base + cnt < m) end_head = (kp[base + cnt] >> KEY_SHIFT) != (kp[base + cnt - 1] >> KEY_SHIFT);
+    const u32 *ag = tileagg + ((size_t)b * TPB + blockIdx.x) * 4;
+    int carryOld = (MODE == MODE_ROUND0) ? -(int)base : (ag[0] ? (int)ag[0] - 1 - (int)base : NOHEAD);
+    int carryNew = ag[1] ? (int)ag[1] - 1 - (int)base : NOHEAD;
+    const u32 lBase = ag[2];
+    __syncthreads();
+    int cls[16];
+    u32 ngrp[16], spos[16];
+    int nheads;
+    tile_classify<MODE>(buf, cnt, prevE, has_prev, carryOld, carryNew, end_head, sm, cls, ngrp, spos, nheads);
+    // S survivors go to the buffer the S-kernel of this round also appends to
+    u64 *sOut = (par[b] ? slA : slB) + (size_t)b * S;
+    tile_emit<MODE>(buf, cnt, cls, ngrp, spos, rank + (size_t)b * S, T + (size_t)b * S,
+                    bwt + (size_t)b * S, nArr[b], sOut, mSn + b, lOutAll + (size_t)b * S, lBase, sm);
+}
+
+// ------------------------------------------------------------------ S-path: sort in LDS
+template <int MODE>
+__global__ __launch_bounds__(RT_THREADS) void k2_ssort(const u64 *slA, const u64 *slB,
+                                                       u64 *slAo, u64 *slBo,
+                                                       const u32 *__restrict__ par,
+                                                       const u32 *__restrict__ mS,
+                                                       const u32 *__restrict__ state, u32 want,
+                                                       u32 *__restrict__ rank,
+                                                       const u8 *__restrict__ T, u8 *__restrict__ bwt,
+                                                       const u32 *__restrict__ nArr,
+                                                       u32 *__restrict__ mSn, u32 *__restrict__ leftg,
+                                                       u32 S) {
+    const u32 b = blockIdx.y;
+    if (state[b] != want) return;
+    const u32 m = mS[b];
+    const u32 t0 = blockIdx.x * SC;
+    if (t0 >= m) return;
+    __shared__ u64 buf[RTILE];
+    __shared__ int sm[16];
+    __shared__ int s_start, s_end;
+    const u64 *in = (par[b] ? slB : slA) + (size_t)b * S;
+    u64 *out = (par[b] ? slAo : slBo) + (size_t)b * S;
+    const int loaded = (int)min((u32)RTILE, m - t0);
+    if (threadIdx.x == 0) {
+        s_start = CROSS;
+        s_end = loaded;
+    }
+    __syncthreads();
+    // load window, find owned span: groups whose head slot is in [t0, t0 + SC)
+    int myStart = CROSS, myEnd = CROSS;
+    for (int q = threadIdx.x; q < RTILE; q += RT_THREADS) {
+        u64 e = ~0ull;
+        if (q < loaded) {
+            e = in[t0 + q];
+            bool head;
+            if (q == 0) head = (t0 == 0) || ((e >> 40) != (in[t0 - 1] >> 40));
+            else head = (e >> 40) != (in[t0 + q - 1] >> 40);
+            if (head) {
+                if (q < SC) myStart = min(myStart, q);
+                else myEnd = min(myEnd, q);
+            }
+        }
+        buf[q] = e;
+    }
+    if (myStart != CROSS) atomicMin(&s_start, myStart);
+    if (myEnd != CROSS) atomicMin(&s_end, myEnd);
+    __syncthreads();
+    const int start = s_start, end = s_end;
+    if (start == CROSS) return; // owns nothing
+    const int cnt = end - start;
+    // blank everything outside the span, then sort ascending: the span lands in buf[0..cnt)
+    int N = 256;
+    while (N < end) N <<= 1;
+    for (int q = threadIdx.x; q < N; q += RT_THREADS)
+        if (q < start || q >= end) buf[q] = ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= N; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int p = threadIdx.x; p < (N >> 1); p += RT_THREADS) {
+                int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                int l = i | j;
+                u64 a = buf[i], c = buf[l];
+                bool asc = (i & k) == 0;
+                if ((a > c) == asc) {
+                    buf[i] = c;
+                    buf[l] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    int cls[16];
+    u32 ngrp[16], spos[16];
+    int nheads;
+    tile_classify<MODE>(buf, cnt, 0, false, NOHEAD, NOHEAD, true, sm, cls, ngrp, spos, nheads);
+    if (MODE == MODE_FINAL && threadIdx.x == 0) atomicAdd(&leftg[b], (u32)nheads);
+    tile_emit<MODE>(buf, cnt, cls, ngrp, spos, rank + (size_t)b * S, T + (size_t)b * S,
+                    bwt + (size_t)b * S, nArr[b], out, mSn + b, (u64 *)nullptr, 0, sm);
+}
+
+// ------------------------------------------------------------------ finish
+__global__ void k2_finish(const u32 *__restrict__ nArr, const u32 *__restrict__ rank,
+                          const u32 *__restrict__ mS, const u32 *__restrict__ mL,
+                          const u32 *__restrict__ state, const u32 *__restrict__ leftg,
+                          const u8 *__restrict__ T, u8 *__restrict__ bwt,
+                          u32 *__restrict__ periodic, u32 *__restrict__ orig, u32 S, u32 nb,
+                          int tie_rule) {
+    u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    u32 n = nArr[b];
+    if (n == 0) { orig[b] = 0; periodic[b] = 1; return; }
+    u32 k = 1;
+    if (state[b] == ST_FIN && leftg[b] > 0) k = (mS[b] + mL[b]) / leftg[b];
+    periodic[b] = k;
+    u32 og = rank[(size_t)b * S];
+    if (k > 1 && k < n && tie_rule == 1) og += k - 1;
+    if (k == n) og = 0; // all-equal block (S/BZip2DivSufSort.swift:3168-3174,3505)
+    orig[b] = og;
+}
+
+// symbol-present bitmap from the block bytes (stage entry bz2hip_bwt has no RLE1 in front)
+__global__ __launch_bounds__(256) void k2_present(const u8 *__restrict__ T,
+                                                  const u32 *__restrict__ nArr,
+                                                  u32 *__restrict__ present, u32 S) {
     const u32 b = blockIdx.y;
     const u32 n = nArr[b];
     const u32 base = blockIdx.x * RTILE;
     if (base >= n) return;
-    const size_t o = (size_t)b * S;
-#pragma unroll 4
+    __shared__ u32 pres[8];
+    if (threadIdx.x < 8) pres[threadIdx.x] = 0;
+    __syncthreads();
     for (int k = 0; k < RT_ITEMS; k++) {
-        u32 j = base + k * RT_THREADS + threadIdx.x;
-        if (j < n) {
-            u32 i = sa[o + j];
-            i = (i == 0) ? n - 1 : i - 1;
-            bwt[o + j] = T[o + i];
+        u32 i = base + k * 256 + threadIdx.x;
+        if (i < n) {
+            u32 v = T[(size_t)b * S + i];
+            atomicOr(&pres[v >> 5], 1u << (v & 31));
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        u32 kper = periodic[b];
-        u32 og = rank[o];
-        if (kper > 1 && kper < n && tie_rule == 1) og += kper - 1;
-        if (kper == n) og = 0; // all-equal block (S/BZip2DivSufSort.swift:3168-3174,3505)
-        orig[b] = og;
-    }
+    __syncthreads();
+    if (threadIdx.x < 8 && pres[threadIdx.x]) atomicOr(&present[b * 8 + threadIdx.x], pres[threadIdx.x]);
 }
 
-__global__ void k2_reset(const u32 *__restrict__ nArr, u32 *nheads, u32 *active, u32 *rounds,
-                         u32 *periodic, u32 *ctl, u32 nb) {
-    u32 b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb) return;
-    atomicAdd(&ctl[2], nArr[b]);
-    nheads[b] = 0;
-    active[b] = nArr[b] > 0 ? 1 : 0;
-    rounds[b] = 0;
-    periodic[b] = 1;
+void run_present(bz2hip_ctx *c, int nb, u32 maxn) {
+    Batch &B = c->batch;
+    if (nb == 0 || maxn == 0) return;
+    HIPCHK(hipMemsetAsync(B.present, 0, (size_t)nb * 8 * sizeof(u32), c->stream));
+    k2_present<<<dim3((maxn + RTILE - 1) / RTILE, nb), 256, 0, c->stream>>>(B.T, B.n, B.present, B.S);
+    KCHECK();
 }
 
 // ------------------------------------------------------------------ driver
-static void radix_sort(bz2hip_ctx *c, int nb, u32 maxn, int passes, u64 *&kin, u32 *&vin,
-                       u64 *&kout, u32 *&vout) {
+static void radix_sort5(bz2hip_ctx *c, int nb, u32 maxcnt, const u32 *cntArr, u64 *a, u64 *bbuf) {
     Batch &B = c->batch;
-    const u32 tiles = (maxn + RTILE - 1) / RTILE;
+    const u32 tiles = (maxcnt + RTILE - 1) / RTILE;
     dim3 grid(tiles, nb);
-    for (int p = 0; p < passes; p++) {
-        int shift = 8 * p;
+    u64 *kin = a, *kout = bbuf;
+    for (int p = 0; p < 5; p++) {
+        int shift = KEY_SHIFT + 8 * p;
         {
             ProfScope ps(c, P_RADIX_HIST);
-            k2_radix_hist<<<grid, RT_THREADS, 0, c->stream>>>(kin, B.n, B.active, B.tilehist, B.S,
+            k2_radix_hist<<<grid, RT_THREADS, 0, c->stream>>>(kin, cntArr, B.state, B.tilehist, B.S,
                                                               B.TPB, shift);
             KCHECK();
         }
         {
             ProfScope ps(c, P_RADIX_SCAN);
-            k2_radix_scan<<<nb, 256, 0, c->stream>>>(B.n, B.active, B.tilehist, B.digitbase, B.TPB);
+            k2_radix_scan<<<nb, 256, 0, c->stream>>>(cntArr, B.state, B.tilehist, B.digitbase, B.TPB);
             KCHECK();
         }
         {
             ProfScope ps(c, P_RADIX_SCATTER);
-            k2_radix_scatter<<<grid, RT_THREADS, 0, c->stream>>>(
-                kin, vin, kout, vout, B.n, B.active, B.tilehist, B.digitbase, B.S, B.TPB, shift);
+            k2_radix_scatter<<<grid, RT_THREADS, 0, c->stream>>>(kin, kout, cntArr, B.state, B.tilehist,
+                                                                 B.digitbase, B.S, B.TPB, shift);
             KCHECK();
         }
         std::swap(kin, kout);
-        std::swap(vin, vout);
     }
 }
 
-static void rerank(bz2hip_ctx *c, int nb, u32 maxn, const u64 *key, const u32 *val) {
+template <int MODE>
+static void lrerank(bz2hip_ctx *c, int nb, u32 maxcnt, const u32 *cntArr, u32 want, const u64 *sorted,
+                    u64 *lout) {
     Batch &B = c->batch;
-    const u32 tiles = (maxn + RTILE - 1) / RTILE;
+    const u32 tiles = (maxcnt + RTILE - 1) / RTILE;
     dim3 grid(tiles, nb);
     ProfScope ps(c, P_BWT_RERANK);
-    k2_rerank_p1<<<grid, RT_THREADS, 0, c->stream>>>(key, B.n, B.active, B.tileagg, B.nheads, B.S,
-                                                     B.TPB);
+    k2_lrerank_p1<MODE><<<grid, RT_THREADS, 0, c->stream>>>(sorted, cntArr, B.state, want, B.tileagg,
+                                                            B.S, B.TPB);
     KCHECK();
-    k2_rerank_p2<<<nb, 256, 0, c->stream>>>(B.n, B.active, B.tileagg, B.TPB);
+    k2_lrerank_p2<<<nb, 256, 0, c->stream>>>(cntArr, B.state, want, B.tileagg, B.mLn, B.leftg,
+                                             MODE == MODE_FINAL ? 1 : 0, B.TPB);
     KCHECK();
-    k2_rerank_p3<<<grid, RT_THREADS, 0, c->stream>>>(key, val, B.n, B.active, B.tileagg, B.grp,
-                                                     B.rank, B.sa, B.S, B.TPB);
+    k2_lrerank_p3<MODE><<<grid, RT_THREADS, 0, c->stream>>>(sorted, lout, B.slA, B.slB, B.par, cntArr,
+                                                            B.state, want, B.tileagg, B.rank, B.T,
+                                                            B.bwt, B.n, B.mSn, B.S, B.TPB);
     KCHECK();
 }
 
-// maxn = largest block length in the batch (host knows it)
+// maxn = upper bound of the block lengths in the batch
 void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
     Batch &B = c->batch;
     if (nb == 0 || maxn == 0) return;
     const u32 tiles = (maxn + RTILE - 1) / RTILE;
     dim3 grid(tiles, nb);
     const int cb = (nb + 255) / 256;
-    HIPCHK(hipMemsetAsync(B.ctl, 0, 4 * sizeof(u32), c->stream));
-    k2_reset<<<cb, 256, 0, c->stream>>>(B.n, B.nheads, B.active, B.rounds, B.periodic, B.ctl, nb);
+    HIPCHK(hipMemsetAsync(B.ctl, 0, 16 * sizeof(u32), c->stream));
+    k2_reset<<<cb, 256, 0, c->stream>>>(B.n, B.present, B.mS, B.mL, B.mSn, B.mLn, B.hcur, B.huse,
+                                        B.state, B.par, B.rounds, B.leftg, B.periodic, B.ctl, nb);
     KCHECK();
     {
         ProfScope ps(c, P_BWT_INIT);
-        k2_init_keys<<<grid, RT_THREADS, 0, c->stream>>>(B.T, B.n, B.keyA, B.valA, B.S);
+        k2_init_keys<<<grid, RT_THREADS, 0, c->stream>>>(B.T, B.n, B.present, B.keyA, B.S);
         KCHECK();
     }
-    u64 *kin = B.keyA, *kout = B.keyB;
-    u32 *vin = B.valA, *vout = B.valB;
-    radix_sort(c, nb, maxn, 8, kin, vin, kout, vout);
-    rerank(c, nb, maxn, kin, vin);
-    u32 h = 8;
+    radix_sort5(c, nb, maxn, B.n, B.keyA, B.keyB); // result in keyB
+    lrerank<MODE_ROUND0>(c, nb, maxn, B.n, ST_ACTIVE, B.keyB, B.keyA);
+    bool first = true;
+    u32 finS = 0, finL = 0;
+    bool anyfin = false;
     for (;;) {
-        HIPCHK(hipMemsetAsync(B.ctl, 0, 2 * sizeof(u32), c->stream));
-        k2_round_ctl<<<cb, 256, 0, c->stream>>>(B.n, B.nheads, B.active, B.rounds, B.periodic, B.ctl,
-                                                nb, h);
+        HIPCHK(hipMemsetAsync(B.ctl, 0, 4 * sizeof(u32), c->stream));
+        HIPCHK(hipMemsetAsync(B.ctl + 7, 0, sizeof(u32), c->stream));
+        k2_ctl<<<cb, 256, 0, c->stream>>>(B.n, B.mS, B.mL, B.mSn, B.mLn, B.hcur, B.huse, B.state, B.par,
+                                          B.rounds, B.ctl, nb);
         KCHECK();
-        u32 hc[3] = {0, 0, 0};
+        u32 hc[9];
         HIPCHK(hipMemcpyAsync(hc, B.ctl, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
-        if (h == 8 && c->profile) { // round 0 sorted every element: 8 passes of 24 B
-            c->prof_bytes[P_RADIX_SCATTER] += 8.0 * 24.0 * (double)hc[2];
-            c->prof_bytes[P_RADIX_HIST] += 8.0 * 8.0 * (double)hc[2];
+        if (first) {
+            if (c->profile) {
+                c->prof_bytes[P_RADIX_SCATTER] += 5.0 * 16.0 * (double)hc[8];
+                c->prof_bytes[P_RADIX_HIST] += 5.0 * 8.0 * (double)hc[8];
+            }
+            c->st_sorted_elems += (u64)hc[8] * 5;
+            first = false;
         }
-        c->st_sorted_elems += (h == 8 ? (u64)hc[2] * 8 : 0) + (u64)hc[1] * (hc[0] ? 5 : 0);
+        anyfin = hc[4] != 0;
+        finS = hc[5];
+        finL = hc[6];
         if (!hc[0]) break;
+        const u32 maxS = hc[1], maxL = hc[2];
+        c->st_sorted_elems += (u64)hc[3] * 5;
+        c->st_s_elems += hc[7];
         if (c->profile) {
-            c->prof_bytes[P_RADIX_SCATTER] += 5.0 * 24.0 * (double)hc[1];
-            c->prof_bytes[P_RADIX_HIST] += 5.0 * 8.0 * (double)hc[1];
+            c->prof_bytes[P_RADIX_SCATTER] += 5.0 * 16.0 * (double)hc[3];
+            c->prof_bytes[P_RADIX_HIST] += 5.0 * 8.0 * (double)hc[3];
         }
         {
             ProfScope ps(c, P_BWT_KEYS);
-            k2_build_keys<<<grid, RT_THREADS, 0, c->stream>>>(B.sa, B.grp, B.rank, B.n, B.active,
-                                                              B.keyA, B.valA, B.S, h);
+            const u32 mx = std::max(maxS, maxL);
+            k2_keys<<<dim3((mx + RTILE - 1) / RTILE, nb, 2), RT_THREADS, 0, c->stream>>>(
+                B.slA, B.slB, B.keyA, B.par, B.mS, B.mL, B.state, B.huse, B.n, B.rank, B.S);
             KCHECK();
         }
-        kin = B.keyA; kout = B.keyB; vin = B.valA; vout = B.valB;
-        radix_sort(c, nb, maxn, 5, kin, vin, kout, vout);
-        rerank(c, nb, maxn, kin, vin);
-        h <<= 1;
+        if (maxS) {
+            ProfScope ps(c, P_BWT_SSORT);
+            k2_ssort<MODE_NORMAL><<<dim3((maxS + SC - 1) / SC, nb), RT_THREADS, 0, c->stream>>>(
+                B.slA, B.slB, B.slA, B.slB, B.par, B.mS, B.state, ST_ACTIVE, B.rank, B.T, B.bwt, B.n,
+                B.mSn, B.leftg, B.S);
+            KCHECK();
+        }
+        if (maxL) {
+            radix_sort5(c, nb, maxL, B.mL, B.keyA, B.keyB);
+            lrerank<MODE_NORMAL>(c, nb, maxL, B.mL, ST_ACTIVE, B.keyB, B.keyA);
+        }
+    }
+    if (anyfin) {
+        // periodic blocks: flush the k-fold ties in list order
+        if (finS) {
+            ProfScope ps(c, P_BWT_SSORT);
+            k2_ssort<MODE_FINAL><<<dim3((finS + SC - 1) / SC, nb), RT_THREADS, 0, c->stream>>>(
+                B.slA, B.slB, B.slA, B.slB, B.par, B.mS, B.state, ST_FIN, B.rank, B.T, B.bwt, B.n,
+                B.mSn, B.leftg, B.S);
+            KCHECK();
+        }
+        if (finL) lrerank<MODE_FINAL>(c, nb, finL, B.mL, ST_FIN, B.keyA, B.keyB);
     }
     {
         ProfScope ps(c, P_BWT_EMIT);
-        k2_emit_bwt<<<grid, RT_THREADS, 0, c->stream>>>(B.T, B.sa, B.rank, B.n, B.periodic, B.bwt,
-                                                        B.orig, B.S, c->opts.tie_rule);
+        k2_finish<<<cb, 256, 0, c->stream>>>(B.n, B.rank, B.mS, B.mL, B.state, B.leftg, B.T, B.bwt,
+                                             B.periodic, B.orig, B.S, nb, c->opts.tie_rule);
         KCHECK();
     }
 }
