@@ -309,6 +309,11 @@ static size_t compress_core(bz2hip_ctx *c, const u8 *d_in, size_t n, int level, 
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     if (c->profile) c->prof_collect();
+    if (getenv("BZ2HIP_DEBUG"))
+        fprintf(stderr, "[bz2hip] blocks=%llu rle_bytes=%llu rounds_sum=%llu S-elems=%llu radix-elem-passes=%llu periodic=%llu\n",
+                (unsigned long long)c->st_blocks, (unsigned long long)c->st_rle_bytes,
+                (unsigned long long)c->st_rounds, (unsigned long long)c->st_s_elems,
+                (unsigned long long)c->st_sorted_elems, (unsigned long long)c->st_periodic);
     return pos;
 }
 

@@ -563,6 +563,24 @@ __global__ __launch_bounds__(RT_THREADS) void k2_lrerank_p3(
 }
 
 // ------------------------------------------------------------------ S-path: sort in LDS
+__device__ __forceinline__ void bitonic_sort_lds(u64 *buf, int N) {
+    for (int k = 2; k <= N; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int p = threadIdx.x; p < (N >> 1); p += RT_THREADS) {
+                int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                int l = i | j;
+                u64 a = buf[i], c = buf[l];
+                bool asc = (i & k) == 0;
+                if ((a > c) == asc) {
+                    buf[i] = c;
+                    buf[l] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(RT_THREADS) void k2_ssort(const u64 *slA, const u64 *slB,
                                                        u64 *slAo, u64 *slBo,
@@ -582,6 +600,7 @@ __global__ __launch_bounds__(RT_THREADS) void k2_ssort(const u64 *slA, const u64
     __shared__ u64 buf[RTILE];
     __shared__ int sm[16];
     __shared__ int s_start, s_end;
+    __shared__ u8 gflag[RTILE];
     const u64 *in = (par[b] ? slB : slA) + (size_t)b * S;
     u64 *out = (par[b] ? slAo : slBo) + (size_t)b * S;
     const int loaded = (int)min((u32)RTILE, m - t0);
@@ -611,27 +630,105 @@ __global__ __launch_bounds__(RT_THREADS) void k2_ssort(const u64 *slA, const u64
     __syncthreads();
     const int start = s_start, end = s_end;
     if (start == CROSS) return; // owns nothing
-    const int cnt = end - start;
-    // blank everything outside the span, then sort ascending: the span lands in buf[0..cnt)
-    int N = 256;
-    while (N < end) N <<= 1;
-    for (int q = threadIdx.x; q < N; q += RT_THREADS)
-        if (q < start || q >= end) buf[q] = ~0ull;
-    __syncthreads();
-    for (int k = 2; k <= N; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int p = threadIdx.x; p < (N >> 1); p += RT_THREADS) {
-                int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
-                int l = i | j;
-                u64 a = buf[i], c = buf[l];
-                bool asc = (i & k) == 0;
-                if ((a > c) == asc) {
-                    buf[i] = c;
-                    buf[l] = a;
+    int cnt = end - start;
+    const int w = wave_id(), lane = lane_id();
+    if (MODE == MODE_NORMAL) {
+        // Groups whose k2 is the same for every member cannot split this round: they pass
+        // through untouched (rank and grp unchanged).  Only the others are compacted and sorted.
+        u64 ev[16];
+        u64 hm[16];
+        u64 dm[16];
+        int lastHead = NOHEAD;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int rb = w * 1024 + k * 64;
+            const int q = rb + lane;
+            bool head = false, diff = false;
+            u64 e = ~0ull;
+            if (q >= start && q < end) {
+                e = buf[q];
+                if (q == start) head = true;
+                else {
+                    u64 ep = buf[q - 1];
+                    head = (e >> 40) != (ep >> 40);
+                    diff = !head && ((e >> KEY_SHIFT) != (ep >> KEY_SHIFT));
                 }
             }
-            __syncthreads();
+            ev[k] = e;
+            u64 a = __ballot(head);
+            hm[k] = a;
+            dm[k] = __ballot(diff);
+            if (a) lastHead = rb + 63 - __clzll((unsigned long long)a);
         }
+        for (int q = threadIdx.x; q < RTILE / 4; q += RT_THREADS) ((u32 *)gflag)[q] = 0;
+        if (lane == 0) sm[w] = lastHead;
+        __syncthreads();
+        int cO = NOHEAD;
+        for (int q = 0; q < w; q++)
+            if (sm[q] != NOHEAD) cO = sm[q];
+        int ohi[16];
+        const u64 le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int rb = w * 1024 + k * 64;
+            u64 mo = hm[k] & le;
+            ohi[k] = mo ? rb + 63 - __clzll((unsigned long long)mo) : cO;
+            if (hm[k]) cO = rb + 63 - __clzll((unsigned long long)hm[k]);
+            if ((dm[k] >> lane) & 1ull) gflag[ohi[k]] = 1;
+        }
+        __syncthreads();
+        // counts
+        u32 cN = 0, cU = 0;
+        u64 nmask[16], umask[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int q = w * 1024 + k * 64 + lane;
+            bool in_span = (q >= start && q < end);
+            bool nonuni = in_span && gflag[ohi[k]] != 0;
+            nmask[k] = __ballot(nonuni);
+            umask[k] = __ballot(in_span && !nonuni);
+            cN += __popcll(nmask[k]);
+            cU += __popcll(umask[k]);
+        }
+        if (lane == 0) {
+            sm[4 + w] = (int)cN;
+            sm[8 + w] = (int)cU;
+        }
+        __syncthreads();
+        const int totN = sm[4] + sm[5] + sm[6] + sm[7];
+        const int totU = sm[8] + sm[9] + sm[10] + sm[11];
+        if (threadIdx.x == 0) sm[12] = totU ? (int)atomicAdd(mSn + b, (u32)totU) : 0;
+        __syncthreads();
+        u32 nRun = 0, uRun = (u32)sm[12];
+        for (int q = 0; q < w; q++) {
+            nRun += (u32)sm[4 + q];
+            uRun += (u32)sm[8 + q];
+        }
+        const u64 lt = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if ((nmask[k] >> lane) & 1ull) buf[nRun + __popcll(nmask[k] & lt)] = ev[k];
+            if ((umask[k] >> lane) & 1ull)
+                out[uRun + __popcll(umask[k] & lt)] = ev[k] & ~(0xFFFFFull << KEY_SHIFT);
+            nRun += __popcll(nmask[k]);
+            uRun += __popcll(umask[k]);
+        }
+        cnt = totN;
+        if (cnt == 0) return;
+        int N = 64;
+        while (N < cnt) N <<= 1;
+        __syncthreads();
+        for (int q = cnt + threadIdx.x; q < N; q += RT_THREADS) buf[q] = ~0ull;
+        __syncthreads();
+        bitonic_sort_lds(buf, N);
+    } else {
+        // FINAL: order inside groups is irrelevant; keep the span in place at buf[0..cnt)
+        int N = 256;
+        while (N < end) N <<= 1;
+        for (int q = threadIdx.x; q < N; q += RT_THREADS)
+            if (q < start || q >= end) buf[q] = ~0ull;
+        __syncthreads();
+        bitonic_sort_lds(buf, N);
     }
     int cls[16];
     u32 ngrp[16], spos[16];
@@ -783,6 +880,8 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
         finL = hc[6];
         if (!hc[0]) break;
         const u32 maxS = hc[1], maxL = hc[2];
+        if (getenv("BZ2HIP_DEBUG") && getenv("BZ2HIP_DEBUG")[0] == '2')
+            fprintf(stderr, "[bz2hip] round: maxS=%u maxL=%u sumS=%u sumL=%u\n", maxS, maxL, hc[7], hc[3]);
         c->st_sorted_elems += (u64)hc[3] * 5;
         c->st_s_elems += hc[7];
         if (c->profile) {
