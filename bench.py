@@ -121,16 +121,25 @@ def main():
                        "roundtrip_ok": ok, "parallelism": f"blocks-sharded x{world}"},
         }
         if prof:
-            sc = prof["radix_scatter"]
+            # dominant kernel class = the one with the most GPU time among those with a defined
+            # algorithmic byte count
+            KERNEL = {"radix_scatter": "k2_radix_scatter", "radix_hist": "k2_radix_hist",
+                      "bwt_keys": "k2_keys", "bwt_ssort": "k2_ssort", "mtf_replay": "k3_mtf_chunks<true>"}
+            dom = max(KERNEL, key=lambda k: prof[k]["ms"])
+            sc = prof[dom]
             launches = max(sc["launches"], 1)
             avg_ms = sc["ms"] / launches
-            alg = sc["alg_bytes"] / launches  # 24 B per element moved (key 8 + index 4, r+w)
+            alg = sc["alg_bytes"] / launches
             achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-            res["roofline"] = {"bound": "hbm", "kernel": "k2_radix_scatter",
+            res["roofline"] = {"bound": "hbm", "kernel": KERNEL[dom],
                                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                                "traffic": None, "avg_launch_ms": round(avg_ms, 4),
                                "launches": launches, "alg_bytes_per_launch": round(alg)}
+            res["kernel_rooflines"] = {
+                KERNEL[k]: {"ms_per_step": round(prof[k]["ms"] / args.steps, 3),
+                            "alg_GBs": round(prof[k]["alg_bytes"] / max(prof[k]["ms"], 1e-9) / 1e6, 1)}
+                for k in KERNEL}
             bwt_cls = ["bwt_init", "radix_hist", "radix_scan", "radix_scatter", "bwt_keys", "bwt_ssort",
                        "bwt_rerank", "bwt_emit"]
             t_bwt = sum(prof[k]["ms"] for k in bwt_cls) * 1e-3 / args.steps

@@ -887,6 +887,9 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
         if (c->profile) {
             c->prof_bytes[P_RADIX_SCATTER] += 5.0 * 16.0 * (double)hc[3];
             c->prof_bytes[P_RADIX_HIST] += 5.0 * 8.0 * (double)hc[3];
+            // keys: read E 8 + gather rank 4 + write E 8; ssort: read E 8 + write E 8 (LDS sort)
+            c->prof_bytes[P_BWT_KEYS] += 20.0 * ((double)hc[3] + (double)hc[7]);
+            c->prof_bytes[P_BWT_SSORT] += 16.0 * (double)hc[7];
         }
         {
             ProfScope ps(c, P_BWT_KEYS);

@@ -33,7 +33,8 @@ __device__ __forceinline__ u32 mtf_step(u32 &L, u32 s) {
     u32 k = (u32)(__ffs(zz) - 1) >> 3;
     u32 pos = (u32)src * 4u + k;
     if (pos != 0) {
-        u32 up = __shfl_up(L, 1, 64);
+        // wave_shr:1 (DPP, gfx9): lane l receives lane l-1, lane 0 keeps `old` = 0
+        u32 up = (u32)__builtin_amdgcn_update_dpp(0, (int)L, 0x138, 0xf, 0xf, false);
         u32 carry = (lane == 0) ? s : (up >> 24);
         u32 shifted = (L << 8) | carry;
         if (lane < src) {
@@ -108,6 +109,55 @@ __global__ __launch_bounds__(256) void k3_mtf_chunks(const u8 *__restrict__ bwt,
         u32 d = wave_reduce_add(__popc(seen));
         if (lane == 0) mtfcnt[(size_t)b * CPB + c] = d;
     }
+}
+
+// Recency list of a chunk without running the MTF: last occurrence of every symbol (LDS
+// atomic max), then rank the present symbols by last occurrence, latest first.
+__global__ __launch_bounds__(256) void k3_mtf_recency(const u8 *__restrict__ bwt,
+                                                      const u32 *__restrict__ nArr,
+                                                      const u32 *__restrict__ present,
+                                                      u8 *__restrict__ mtfrec,
+                                                      u32 *__restrict__ mtfcnt, u32 S, u32 CPB) {
+    const u32 b = blockIdx.y;
+    const u32 n = nArr[b];
+    __shared__ u8 smap[256];
+    __shared__ __attribute__((aligned(16))) u32 last[MTF_WG_CHUNKS][256];
+    __shared__ __attribute__((aligned(16))) u8 recl[MTF_WG_CHUNKS][256];
+    build_symbol_map(present + b * 8, smap);
+    for (int q = threadIdx.x; q < MTF_WG_CHUNKS * 256; q += 256) (&last[0][0])[q] = 0;
+    __syncthreads();
+    const int w = wave_id(), lane = lane_id();
+    const u32 c = blockIdx.x * MTF_WG_CHUNKS + w;
+    const u32 cbase = c * MTF_CHUNK;
+    if (cbase >= n) return;
+    const u32 cend = min(cbase + MTF_CHUNK, n);
+    const u8 *src = bwt + (size_t)b * S;
+    for (u32 j = cbase + lane; j < cend; j += 64) atomicMax(&last[w][smap[src[j]]], j - cbase + 1);
+    // wave-local: LDS operations of one wave complete in order
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    u32 mine[4], r[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; k++) mine[k] = last[w][lane * 4 + k];
+    const uint4 *lv = (const uint4 *)&last[w][0];
+    for (int t = 0; t < 64; t++) {
+        uint4 v = lv[t];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            r[k] += (v.x > mine[k]) + (v.y > mine[k]) + (v.z > mine[k]) + (v.w > mine[k]);
+    }
+    u32 d = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (mine[k]) {
+            recl[w][r[k]] = (u8)(lane * 4 + k);
+            d++;
+        }
+    d = wave_reduce_add(d);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    ((u32 *)(mtfrec + ((size_t)b * CPB + c) * 256))[lane] = ((const u32 *)&recl[w][0])[lane];
+    if (lane == 0) mtfcnt[(size_t)b * CPB + c] = d;
 }
 
 // one wave per block: turn recency lists into entry states, in place
@@ -390,8 +440,7 @@ void run_mtf(bz2hip_ctx *c, int nb, u32 maxn) {
     dim3 gridc((chunks + MTF_WG_CHUNKS - 1) / MTF_WG_CHUNKS, nb);
     {
         ProfScope ps(c, P_MTF_STATE);
-        k3_mtf_chunks<false><<<gridc, 256, 0, c->stream>>>(B.bwt, B.n, B.present, B.mtfrec, B.mtfcnt,
-                                                            B.mtfpos, B.S, CPB);
+        k3_mtf_recency<<<gridc, 256, 0, c->stream>>>(B.bwt, B.n, B.present, B.mtfrec, B.mtfcnt, B.S, CPB);
         KCHECK();
     }
     {
@@ -400,7 +449,7 @@ void run_mtf(bz2hip_ctx *c, int nb, u32 maxn) {
         KCHECK();
     }
     {
-        ProfScope ps(c, P_MTF_REPLAY);
+        ProfScope ps(c, P_MTF_REPLAY, 2.0 * (double)maxn * nb); // read bwt 1 + write pos 1 (upper bound: slots)
         k3_mtf_chunks<true><<<gridc, 256, 0, c->stream>>>(B.bwt, B.n, B.present, B.mtfrec, B.mtfcnt,
                                                            B.mtfpos, B.S, CPB);
         KCHECK();
