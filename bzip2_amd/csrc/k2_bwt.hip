@@ -26,6 +26,22 @@
 #define KEY_SHIFT 20
 #define E_IMASK 0xFFFFFull
 
+// XCD-aware launch: workgroups are dealt round-robin over the 8 XCDs by linear id, so block b
+// is handled only by ids congruent to b mod 8: its rank array / lists stay in one XCD's L2.
+#define XCD_MAP(gtiles, gnb)                                   \
+    u32 bz_t, bz_b;                                            \
+    if ((gnb) & 0x80000000u) {                                 \
+        bz_t = blockIdx.x % (gtiles);                          \
+        bz_b = blockIdx.x / (gtiles);                          \
+    } else {                                                   \
+        const u32 L_ = blockIdx.x, idx_ = L_ >> 3;             \
+        bz_b = (L_ & 7u) + 8u * (idx_ / (gtiles));             \
+        bz_t = idx_ % (gtiles);                                \
+    }                                                          \
+    if (bz_b >= ((gnb) & 0x7fffffffu)) return;
+// plain mapping with the same interface (compute-bound kernels prefer even spread over XCDs)
+static inline u32 xcd_grid(u32 tiles, u32 nb) { return 8u * tiles * ((nb + 7u) / 8u); }
+
 enum { ST_DONE = 0, ST_ACTIVE = 1, ST_FIN = 2 };
 enum { MODE_NORMAL = 0, MODE_ROUND0 = 1, MODE_FINAL = 2 };
 enum { CLS_NONE = 0, CLS_SINGLE = 1, CLS_SMALL = 2, CLS_LKEEP = 3 };
@@ -83,10 +99,11 @@ __global__ void k2_ctl(const u32 *__restrict__ nArr, u32 *mS, u32 *mL, u32 *mSn,
 __global__ __launch_bounds__(RT_THREADS) void k2_init_keys(const u8 *__restrict__ T,
                                                            const u32 *__restrict__ nArr,
                                                            const u32 *__restrict__ present,
-                                                           u64 *__restrict__ key, u32 S) {
-    const u32 b = blockIdx.y;
+                                                           u64 *__restrict__ key, u32 S, u32 gtiles, u32 gnb) {
+    XCD_MAP(gtiles, gnb)
+    const u32 b = bz_b;
     const u32 n = nArr[b];
-    const u32 base = blockIdx.x * RTILE;
+    const u32 base = bz_t * RTILE;
     __shared__ u8 smap[256];
     __shared__ u32 s_bps;
     if (threadIdx.x < 256) {
@@ -127,11 +144,12 @@ __global__ __launch_bounds__(RT_THREADS) void k2_radix_hist(const u64 *__restric
                                                             const u32 *__restrict__ cntArr,
                                                             const u32 *__restrict__ state,
                                                             u32 *__restrict__ tilehist, u32 S,
-                                                            u32 TPB, int shift) {
-    const u32 b = blockIdx.y;
+                                                            u32 TPB, int shift, u32 gtiles, u32 gnb) {
+    XCD_MAP(gtiles, gnb)
+    const u32 b = bz_b;
     if (state[b] != ST_ACTIVE) return;
     const u32 n = cntArr[b];
-    const u32 base = blockIdx.x * RTILE;
+    const u32 base = bz_t * RTILE;
     if (base >= n) return;
     __shared__ u32 hist[256];
     hist[threadIdx.x] = 0;
@@ -143,7 +161,7 @@ __global__ __launch_bounds__(RT_THREADS) void k2_radix_hist(const u64 *__restric
         if (i < n) atomicAdd(&hist[(u32)(kp[i] >> shift) & 255u], 1u);
     }
     __syncthreads();
-    tilehist[((size_t)b * TPB + blockIdx.x) * 256 + threadIdx.x] = hist[threadIdx.x];
+    tilehist[((size_t)b * TPB + bz_t) * 256 + threadIdx.x] = hist[threadIdx.x];
 }
 
 __global__ __launch_bounds__(256) void k2_radix_scan(const u32 *__restrict__ cntArr,
@@ -181,11 +199,12 @@ __device__ __forceinline__ u64 match8(u32 d, bool valid) {
 __global__ __launch_bounds__(RT_THREADS) void k2_radix_scatter(
     const u64 *__restrict__ keyIn, u64 *__restrict__ keyOut, const u32 *__restrict__ cntArr,
     const u32 *__restrict__ state, const u32 *__restrict__ tilehist,
-    const u32 *__restrict__ digitbase, u32 S, u32 TPB, int shift) {
-    const u32 b = blockIdx.y;
+    const u32 *__restrict__ digitbase, u32 S, u32 TPB, int shift, u32 gtiles, u32 gnb) {
+    XCD_MAP(gtiles, gnb)
+    const u32 b = bz_b;
     if (state[b] != ST_ACTIVE) return;
     const u32 n = cntArr[b];
-    const u32 base = blockIdx.x * RTILE;
+    const u32 base = bz_t * RTILE;
     if (base >= n) return;
     __shared__ u32 whist[4][256];
     __shared__ u32 gofs[256];
@@ -225,7 +244,7 @@ __global__ __launch_bounds__(RT_THREADS) void k2_radix_scatter(
             whist[q][d] = run;
             run += c;
         }
-        gofs[d] = digitbase[b * 256 + d] + tilehist[((size_t)b * TPB + blockIdx.x) * 256 + d];
+        gofs[d] = digitbase[b * 256 + d] + tilehist[((size_t)b * TPB + bz_t) * 256 + d];
     }
     __syncthreads();
     u64 *ko = keyOut + (size_t)b * S;
@@ -249,13 +268,16 @@ __global__ __launch_bounds__(RT_THREADS) void k2_keys(u64 *__restrict__ slA, u64
                                                       const u32 *__restrict__ state,
                                                       const u32 *__restrict__ huse,
                                                       const u32 *__restrict__ nArr,
-                                                      const u32 *__restrict__ rank, u32 S) {
-    const u32 b = blockIdx.y;
+                                                      const u32 *__restrict__ rank, u32 S, u32 gtiles, u32 gnb) {
+    XCD_MAP(2 * gtiles, gnb)
+    const u32 b = bz_b;
+    const u32 zsel = bz_t / gtiles;
+    bz_t = bz_t % gtiles;
     if (state[b] != ST_ACTIVE) return;
-    const u32 m = blockIdx.z ? mL[b] : mS[b];
-    const u32 base = blockIdx.x * RTILE;
+    const u32 m = zsel ? mL[b] : mS[b];
+    const u32 base = bz_t * RTILE;
     if (base >= m) return;
-    u64 *list = (blockIdx.z ? keyA : (par[b] ? slB : slA)) + (size_t)b * S;
+    u64 *list = (zsel ? keyA : (par[b] ? slB : slA)) + (size_t)b * S;
     const u32 n = nArr[b], h = huse[b];
     const u32 *rk = rank + (size_t)b * S;
 #pragma unroll 4
@@ -438,11 +460,12 @@ template <int MODE>
 __global__ __launch_bounds__(RT_THREADS) void k2_lrerank_p1(const u64 *__restrict__ key,
                                                             const u32 *__restrict__ cntArr,
                                                             const u32 *__restrict__ state, u32 want,
-                                                            u32 *__restrict__ tileagg, u32 S, u32 TPB) {
-    const u32 b = blockIdx.y;
+                                                            u32 *__restrict__ tileagg, u32 S, u32 TPB, u32 gtiles, u32 gnb) {
+    XCD_MAP(gtiles, gnb)
+    const u32 b = bz_b;
     if (state[b] != want) return;
     const u32 m = cntArr[b];
-    const u32 base = blockIdx.x * RTILE;
+    const u32 base = bz_t * RTILE;
     if (base >= m) return;
     __shared__ u64 buf[RTILE];
     __shared__ int sm[16];
@@ -482,7 +505,7 @@ __global__ __launch_bounds__(RT_THREADS) void k2_lrerank_p1(const u64 *__restric
     u32 tN = block_reduce_max<RT_THREADS>((u32)lastNew, red);
     u32 tK = block_reduce_add<RT_THREADS>(keep, red);
     if (threadIdx.x == 0) {
-        u32 *o = tileagg + ((size_t)b * TPB + blockIdx.x) * 4;
+        u32 *o = tileagg + ((size_t)b * TPB + bz_t) * 4;
         o[0] = tO; o[1] = tN; o[2] = tK; o[3] = (u32)nheads;
     }
 }
@@ -532,11 +555,12 @@ __global__ __launch_bounds__(RT_THREADS) void k2_lrerank_p3(
     const u32 *__restrict__ par, const u32 *__restrict__ cntArr,
     const u32 *__restrict__ state, u32 want, const u32 *__restrict__ tileagg,
     u32 *__restrict__ rank, const u8 *__restrict__ T, u8 *__restrict__ bwt,
-    const u32 *__restrict__ nArr, u32 *__restrict__ mSn, u32 S, u32 TPB) {
-    const u32 b = blockIdx.y;
+    const u32 *__restrict__ nArr, u32 *__restrict__ mSn, u32 S, u32 TPB, u32 gtiles, u32 gnb) {
+    XCD_MAP(gtiles, gnb)
+    const u32 b = bz_b;
     if (state[b] != want) return;
     const u32 m = cntArr[b];
-    const u32 base = blockIdx.x * RTILE;
+    const u32 base = bz_t * RTILE;
     if (base >= m) return;
     __shared__ u64 buf[RTILE];
     __shared__ int sm[16];
@@ -547,7 +571,7 @@ __global__ __launch_bounds__(RT_THREADS) void k2_lrerank_p3(
     const u64 prevE = has_prev ? kp[base - 1] : 0;
     bool end_head = true;
     if (base + cnt < m) end_head = (kp[base + cnt] >> KEY_SHIFT) != (kp[base + cnt - 1] >> KEY_SHIFT);
-    const u32 *ag = tileagg + ((size_t)b * TPB + blockIdx.x) * 4;
+    const u32 *ag = tileagg + ((size_t)b * TPB + bz_t) * 4;
     int carryOld = (MODE == MODE_ROUND0) ? -(int)base : (ag[0] ? (int)ag[0] - 1 - (int)base : NOHEAD);
     int carryNew = ag[1] ? (int)ag[1] - 1 - (int)base : NOHEAD;
     const u32 lBase = ag[2];
@@ -582,7 +606,7 @@ __device__ __forceinline__ void bitonic_sort_lds(u64 *buf, int N) {
 }
 
 template <int MODE>
-__global__ __launch_bounds__(RT_THREADS) void k2_ssort(const u64 *slA, const u64 *slB,
+__global__ __launch_bounds__(RT_THREADS, 4) void k2_ssort(const u64 *slA, const u64 *slB,
                                                        u64 *slAo, u64 *slBo,
                                                        const u32 *__restrict__ par,
                                                        const u32 *__restrict__ mS,
@@ -591,11 +615,12 @@ __global__ __launch_bounds__(RT_THREADS) void k2_ssort(const u64 *slA, const u64
                                                        const u8 *__restrict__ T, u8 *__restrict__ bwt,
                                                        const u32 *__restrict__ nArr,
                                                        u32 *__restrict__ mSn, u32 *__restrict__ leftg,
-                                                       u32 S) {
-    const u32 b = blockIdx.y;
+                                                       u32 S, u32 gtiles, u32 gnb) {
+    XCD_MAP(gtiles, gnb)
+    const u32 b = bz_b;
     if (state[b] != want) return;
     const u32 m = mS[b];
-    const u32 t0 = blockIdx.x * SC;
+    const u32 t0 = bz_t * SC;
     if (t0 >= m) return;
     __shared__ u64 buf[RTILE];
     __shared__ int sm[16];
@@ -762,10 +787,11 @@ __global__ void k2_finish(const u32 *__restrict__ nArr, const u32 *__restrict__ 
 // symbol-present bitmap from the block bytes (stage entry bz2hip_bwt has no RLE1 in front)
 __global__ __launch_bounds__(256) void k2_present(const u8 *__restrict__ T,
                                                   const u32 *__restrict__ nArr,
-                                                  u32 *__restrict__ present, u32 S) {
-    const u32 b = blockIdx.y;
+                                                  u32 *__restrict__ present, u32 S, u32 gtiles, u32 gnb) {
+    XCD_MAP(gtiles, gnb)
+    const u32 b = bz_b;
     const u32 n = nArr[b];
-    const u32 base = blockIdx.x * RTILE;
+    const u32 base = bz_t * RTILE;
     if (base >= n) return;
     __shared__ u32 pres[8];
     if (threadIdx.x < 8) pres[threadIdx.x] = 0;
@@ -785,11 +811,16 @@ void run_present(bz2hip_ctx *c, int nb, u32 maxn) {
     Batch &B = c->batch;
     if (nb == 0 || maxn == 0) return;
     HIPCHK(hipMemsetAsync(B.present, 0, (size_t)nb * 8 * sizeof(u32), c->stream));
-    k2_present<<<dim3((maxn + RTILE - 1) / RTILE, nb), 256, 0, c->stream>>>(B.T, B.n, B.present, B.S);
+    k2_present<<<xcd_grid((maxn + RTILE - 1) / RTILE, nb), 256, 0, c->stream>>>(B.T, B.n, B.present, B.S,
+                                                                                   (maxn + RTILE - 1) / RTILE, nb);
     KCHECK();
 }
 
 // ------------------------------------------------------------------ driver
+// bit set = plain (x-fastest) mapping for that kernel family; default: S-sort only
+static u32 g_plain_mask = 2;
+static inline u32 nbarg(u32 nb, u32 bit) { return (g_plain_mask & bit) ? (nb | 0x80000000u) : nb; }
+
 static void radix_sort5(bz2hip_ctx *c, int nb, u32 maxcnt, const u32 *cntArr, u64 *a, u64 *bbuf) {
     Batch &B = c->batch;
     const u32 tiles = (maxcnt + RTILE - 1) / RTILE;
@@ -799,8 +830,8 @@ static void radix_sort5(bz2hip_ctx *c, int nb, u32 maxcnt, const u32 *cntArr, u6
         int shift = KEY_SHIFT + 8 * p;
         {
             ProfScope ps(c, P_RADIX_HIST);
-            k2_radix_hist<<<grid, RT_THREADS, 0, c->stream>>>(kin, cntArr, B.state, B.tilehist, B.S,
-                                                              B.TPB, shift);
+            k2_radix_hist<<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(kin, cntArr, B.state, B.tilehist,
+                                                                             B.S, B.TPB, shift, tiles, nbarg(nb, 8));
             KCHECK();
         }
         {
@@ -810,8 +841,8 @@ static void radix_sort5(bz2hip_ctx *c, int nb, u32 maxcnt, const u32 *cntArr, u6
         }
         {
             ProfScope ps(c, P_RADIX_SCATTER);
-            k2_radix_scatter<<<grid, RT_THREADS, 0, c->stream>>>(kin, kout, cntArr, B.state, B.tilehist,
-                                                                 B.digitbase, B.S, B.TPB, shift);
+            k2_radix_scatter<<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(
+                kin, kout, cntArr, B.state, B.tilehist, B.digitbase, B.S, B.TPB, shift, tiles, nbarg(nb, 8));
             KCHECK();
         }
         std::swap(kin, kout);
@@ -825,15 +856,15 @@ static void lrerank(bz2hip_ctx *c, int nb, u32 maxcnt, const u32 *cntArr, u32 wa
     const u32 tiles = (maxcnt + RTILE - 1) / RTILE;
     dim3 grid(tiles, nb);
     ProfScope ps(c, P_BWT_RERANK);
-    k2_lrerank_p1<MODE><<<grid, RT_THREADS, 0, c->stream>>>(sorted, cntArr, B.state, want, B.tileagg,
-                                                            B.S, B.TPB);
+    k2_lrerank_p1<MODE><<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(sorted, cntArr, B.state, want,
+                                                                           B.tileagg, B.S, B.TPB, tiles, nbarg(nb, 4));
     KCHECK();
     k2_lrerank_p2<<<nb, 256, 0, c->stream>>>(cntArr, B.state, want, B.tileagg, B.mLn, B.leftg,
                                              MODE == MODE_FINAL ? 1 : 0, B.TPB);
     KCHECK();
-    k2_lrerank_p3<MODE><<<grid, RT_THREADS, 0, c->stream>>>(sorted, lout, B.slA, B.slB, B.par, cntArr,
+    k2_lrerank_p3<MODE><<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(sorted, lout, B.slA, B.slB, B.par, cntArr,
                                                             B.state, want, B.tileagg, B.rank, B.T,
-                                                            B.bwt, B.n, B.mSn, B.S, B.TPB);
+                                                            B.bwt, B.n, B.mSn, B.S, B.TPB, tiles, nbarg(nb, 4));
     KCHECK();
 }
 
@@ -841,8 +872,8 @@ static void lrerank(bz2hip_ctx *c, int nb, u32 maxcnt, const u32 *cntArr, u32 wa
 void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
     Batch &B = c->batch;
     if (nb == 0 || maxn == 0) return;
+    if (const char *pm = getenv("BZ2HIP_PLAIN")) g_plain_mask = (u32)atoi(pm);
     const u32 tiles = (maxn + RTILE - 1) / RTILE;
-    dim3 grid(tiles, nb);
     const int cb = (nb + 255) / 256;
     HIPCHK(hipMemsetAsync(B.ctl, 0, 16 * sizeof(u32), c->stream));
     k2_reset<<<cb, 256, 0, c->stream>>>(B.n, B.present, B.mS, B.mL, B.mSn, B.mLn, B.hcur, B.huse,
@@ -850,7 +881,8 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
     KCHECK();
     {
         ProfScope ps(c, P_BWT_INIT);
-        k2_init_keys<<<grid, RT_THREADS, 0, c->stream>>>(B.T, B.n, B.present, B.keyA, B.S);
+        k2_init_keys<<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(B.T, B.n, B.present, B.keyA, B.S,
+                                                                        tiles, nb);
         KCHECK();
     }
     radix_sort5(c, nb, maxn, B.n, B.keyA, B.keyB); // result in keyB
@@ -894,15 +926,15 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
         {
             ProfScope ps(c, P_BWT_KEYS);
             const u32 mx = std::max(maxS, maxL);
-            k2_keys<<<dim3((mx + RTILE - 1) / RTILE, nb, 2), RT_THREADS, 0, c->stream>>>(
-                B.slA, B.slB, B.keyA, B.par, B.mS, B.mL, B.state, B.huse, B.n, B.rank, B.S);
+            k2_keys<<<xcd_grid(2 * ((mx + RTILE - 1) / RTILE), nb), RT_THREADS, 0, c->stream>>>(
+                B.slA, B.slB, B.keyA, B.par, B.mS, B.mL, B.state, B.huse, B.n, B.rank, B.S, (mx + RTILE - 1) / RTILE, nbarg(nb, 1));
             KCHECK();
         }
         if (maxS) {
             ProfScope ps(c, P_BWT_SSORT);
-            k2_ssort<MODE_NORMAL><<<dim3((maxS + SC - 1) / SC, nb), RT_THREADS, 0, c->stream>>>(
+            k2_ssort<MODE_NORMAL><<<xcd_grid((maxS + SC - 1) / SC, nb), RT_THREADS, 0, c->stream>>>(
                 B.slA, B.slB, B.slA, B.slB, B.par, B.mS, B.state, ST_ACTIVE, B.rank, B.T, B.bwt, B.n,
-                B.mSn, B.leftg, B.S);
+                B.mSn, B.leftg, B.S, (maxS + SC - 1) / SC, nbarg(nb, 2));
             KCHECK();
         }
         if (maxL) {
@@ -914,9 +946,9 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
         // periodic blocks: flush the k-fold ties in list order
         if (finS) {
             ProfScope ps(c, P_BWT_SSORT);
-            k2_ssort<MODE_FINAL><<<dim3((finS + SC - 1) / SC, nb), RT_THREADS, 0, c->stream>>>(
+            k2_ssort<MODE_FINAL><<<xcd_grid((finS + SC - 1) / SC, nb), RT_THREADS, 0, c->stream>>>(
                 B.slA, B.slB, B.slA, B.slB, B.par, B.mS, B.state, ST_FIN, B.rank, B.T, B.bwt, B.n,
-                B.mSn, B.leftg, B.S);
+                B.mSn, B.leftg, B.S, (finS + SC - 1) / SC, nbarg(nb, 2));
             KCHECK();
         }
         if (finL) lrerank<MODE_FINAL>(c, nb, finL, B.mL, ST_FIN, B.keyA, B.keyB);
