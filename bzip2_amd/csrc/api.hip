@@ -442,8 +442,10 @@ extern "C" int bz2hip_stream_begin(bz2hip_ctx *c, int level) {
     c->s_out_pos = 0;
     c->s_stream_crc = 0;
     c->s_bitbuf = 0;
-    c->s_bitcnt = -1; // -1: stream header not written yet
-    // stream header is produced by the first flush (or by finish on empty input)
+    c->s_bitcnt = 0;
+    // the stream header reaches the sink at construction time (S/BZip2OutputStream.swift:181-184)
+    const u8 hdr[4] = {0x42, 0x5a, 0x68, (u8)('0' + level)};
+    c->s_out.insert(c->s_out.end(), hdr, hdr + 4);
     return BZ2HIP_OK;
 }
 
@@ -456,7 +458,7 @@ static int stream_flush(bz2hip_ctx *c, bool final) {
         if (n) HIPCHK(hipMemcpyAsync(c->h_in, c->s_in.data(), n, hipMemcpyHostToDevice, c->stream));
         size_t zlen = bound & ~(size_t)3;
         HIPCHK(hipMemsetAsync(c->h_out, 0, zlen, c->stream));
-        const bool header = c->s_bitcnt < 0; // stream header still to be written
+        const bool header = false; // already emitted by bz2hip_stream_begin
         u64 bitpos = header ? 32 : (u64)c->s_bitcnt;
         u32 scrc = c->s_stream_crc;
         size_t used = compress_core(c, c->h_in, n, c->s_level, c->h_out, zlen, &bitpos, &scrc, header, final);
