@@ -202,6 +202,7 @@ class BZip2OutputStream : public java::io::OutputStream {
         if (blockSizeMultiplier < 1 || blockSizeMultiplier > 9)
             throw IllegalArgumentException("Invalid BZip2 block size " + std::to_string(blockSizeMultiplier));
         check(bz2hip_stream_begin(ctx.h, blockSizeMultiplier));
+        drain(); // the 4 header bytes reach the sink at construction (:181-184)
     }
     explicit BZip2OutputStream(java::io::OutputStream &out) : BZip2OutputStream(out, 9) {}       // :197-199
     void write(int value) override {                                                              // :67-79
