@@ -141,7 +141,7 @@ def main():
                             "alg_GBs": round(prof[k]["alg_bytes"] / max(prof[k]["ms"], 1e-9) / 1e6, 1)}
                 for k in KERNEL}
             bwt_cls = ["bwt_init", "radix_hist", "radix_scan", "radix_scatter", "bwt_keys", "bwt_ssort",
-                       "bwt_rerank", "bwt_emit"]
+                       "bwt_rerank", "bwt_emit", "bwt_tie"]
             t_bwt = sum(prof[k]["ms"] for k in bwt_cls) * 1e-3 / args.steps
             n_rle = stats["rle_bytes"]
             # B_bwt = 15 n + 140 R n, with our depth-8 first sort counted as R0 = 3

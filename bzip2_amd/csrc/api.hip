@@ -35,6 +35,7 @@ static void ensure_batch(bz2hip_ctx *c, int level, int nb_needed) {
     Batch &N = c->batch;
     N.NB = want;
     N.S = S;
+    N.level = level;
     N.TPB = S / RTILE;
     const size_t nb = (size_t)want;
     const size_t S2 = S + 64;
@@ -718,7 +719,7 @@ extern "C" int bz2hip_rle1_split(bz2hip_ctx *c, const uint8_t *in, size_t n, int
 // ------------------------------------------------------------------ profiling
 static const char *k_prof_names[P_COUNT] = {
     "rle1_scan", "rle1_split", "rle1_emit", "crc", "bwt_init", "radix_hist", "radix_scan",
-    "radix_scatter", "bwt_keys", "bwt_ssort", "bwt_rerank", "bwt_emit", "mtf_state", "mtf_compose",
+    "radix_scatter", "bwt_keys", "bwt_ssort", "bwt_rerank", "bwt_emit", "bwt_tie", "mtf_state", "mtf_compose",
     "mtf_replay", "rle2", "huf_seed", "huf_select", "huf_lengths", "huf_codes", "huf_header",
     "pack", "frame"};
 

@@ -118,6 +118,7 @@ enum ProfClass {
     P_BWT_SSORT,
     P_BWT_RERANK,
     P_BWT_EMIT,
+    P_BWT_TIE,
     P_MTF_STATE,
     P_MTF_COMPOSE,
     P_MTF_REPLAY,

@@ -49,6 +49,7 @@ struct Batch {
     u32 *ctl = nullptr;       // [4] device control words (any_active, ...)
     u8 *bwt = nullptr;        // [NB][S]
     u32 *orig = nullptr;      // [NB]
+    int level = 0;            // declared block size / 100000 the batch was sized for
     u32 *periodic = nullptr;  // [NB] period count k (1 = aperiodic)
     // MTF / RLE2
     u8 *mtfrec = nullptr;     // [NB][chunks][256] recency lists, then entry states
@@ -106,6 +107,7 @@ struct bz2hip_ctx {
     double prof_bytes[P_COUNT] = {0};
     // stats of the last call
     u64 st_blocks = 0, st_rounds = 0, st_rle_bytes = 0, st_periodic = 0;
+    u64 st_tie_traps = 0; // periodic blocks on which the reference would have indexed past its array
     u64 st_s_elems = 0;      // elements sorted by the LDS (S) path, summed over rounds
     u64 st_sorted_elems = 0; // sum over radix passes of elements moved
     u64 st_nr = 0;           // sum over blocks of n_b * doubling rounds_b
@@ -158,7 +160,7 @@ struct ProfScope {
     ~ProfScope() {
         if (c->profile && e0) {
             hipEvent_t e1 = c->get_event();
-            hipEventRecord(e1, c->stream);
+            (void)hipEventRecord(e1, c->stream);
             c->prof_pending.push_back({cls, e0, e1});
         }
     }
@@ -169,6 +171,7 @@ struct ProfScope {
 // stage drivers (each in its own .hip file)
 void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn);                       // k2_bwt.hip
 void run_present(bz2hip_ctx *c, int nb, u32 maxn);                     // k2_bwt.hip
+void run_tie(bz2hip_ctx *c, int nb);                                   // k2_tie.hip
 void run_mtf(bz2hip_ctx *c, int nb, u32 maxn);                         // k3_mtf.hip
 void run_huffman(bz2hip_ctx *c, int nb, u32 maxmtf);                   // k4_huffman.hip
 // writes blocks at absolute bit offsets into d_out (zeroed); first_bit = bit offset of block 0

@@ -779,7 +779,7 @@ __global__ void k2_finish(const u32 *__restrict__ nArr, const u32 *__restrict__ 
     if (state[b] == ST_FIN && leftg[b] > 0) k = (mS[b] + mL[b]) / leftg[b];
     periodic[b] = k;
     u32 og = rank[(size_t)b * S];
-    if (k > 1 && k < n && tie_rule == 1) og += k - 1;
+    if (k > 1 && k < n && tie_rule == BZ2HIP_TIE_LAST) og += k - 1;
     if (k == n) og = 0; // all-equal block (S/BZip2DivSufSort.swift:3168-3174,3505)
     orig[b] = og;
 }
@@ -959,4 +959,6 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
                                              B.periodic, B.orig, B.S, nb, c->opts.tie_rule);
         KCHECK();
     }
+    // periodic blocks: the reference's origin pointer depends on its sorter's tie order (k2_tie.hip)
+    if (anyfin && c->opts.tie_rule == BZ2HIP_TIE_REFERENCE) run_tie(c, nb);
 }

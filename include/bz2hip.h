@@ -33,10 +33,18 @@ extern "C" {
 
 typedef struct bz2hip_ctx bz2hip_ctx;
 
+/* A block that is a perfect power w^k has k rotations equal to rotation 0; any of their sorted
+ * positions decodes correctly, the reference emits the one its sorter happens to produce
+ * (S/BZip2DivSufSort.swift:3472-3477).  REFERENCE replays that sorter on the device for such
+ * blocks (one lane per block, slow but exact); FIRST/LAST skip it. */
+#define BZ2HIP_TIE_REFERENCE 0
+#define BZ2HIP_TIE_FIRST 1
+#define BZ2HIP_TIE_LAST 2
+
 typedef struct bz2hip_opts {
     int device;            /* HIP device ordinal; -1 = current device */
     int max_batch_blocks;  /* blocks sorted per batch (0 = default 256) */
-    int tie_rule;          /* origin-pointer rule on periodic blocks (0 = default) */
+    int tie_rule;          /* origin pointer of periodic blocks (block == w^k): BZ2HIP_TIE_* */
     int profile;           /* 1 = record HIP events per kernel class (bz2hip_profile_*) */
 } bz2hip_opts;
 

@@ -108,12 +108,56 @@ size_t orc_rle1_block(const uint8_t *in, size_t n_in, int block_size, uint8_t *b
 
 /* ------------------------------------------------------------------ BWT (tier 1) */
 static int g_tie_rule = 0;
+static int g_sa_block_size = 0; /* declared block size for tier 2's array length (0 = derive from n) */
+void orc_set_block_size(int block_size) { g_sa_block_size = block_size; }
 void orc_set_tie_rule(int rule) { g_tie_rule = rule; }
+
+/* tier 2 (divsufsort_restate.c): the reference's own sorter, restated.  T[n] is written. */
+static int g_traps = 0;
+int orc_divsufsort_traps(void) { return g_traps; }
+
+void orc_bwt_divsufsort(uint8_t *T, int n, uint8_t *bwt, int *orig) {
+    /* the reference's array: blockSize + 1 ints, zeroed (S/BZip2BlockCompressor.swift:318);
+     * blockSize = the smallest declared size that can hold n (n <= blockSize, :198-227) */
+    int sa_len = (n <= 100000 ? 100000 : (n + 99999) / 100000 * 100000) + 1;
+    if (g_sa_block_size >= n && g_sa_block_size > 0) sa_len = g_sa_block_size + 1;
+    int *sa = (int *)calloc((size_t)sa_len, sizeof(int));
+    int trap = 0;
+    if (n > 0) T[n] = T[0]; /* S/BZip2BlockCompressor.swift:266 */
+    *orig = orc_divsufsort_bwt(T, sa, n, sa_len, &trap);
+    if (trap) __sync_fetch_and_add(&g_traps, 1);
+    for (int i = 0; i < n; i++) bwt[i] = (uint8_t)sa[i];
+    /* all-equal block: the reference leaves SA[i] = i (S/BZip2DivSufSort.swift:3168-3174), which the
+     * one-symbol map of the MTF stage turns into symbol 0 for every position
+     * (S/BZip2MTFAndRLE2StageEncoder.swift:45-54,66); report the equivalent byte string. */
+    int alleq = 1;
+    for (int i = 1; i < n && alleq; i++) alleq = (T[i] == T[0]);
+    if (alleq) for (int i = 0; i < n; i++) bwt[i] = T[0];
+    free(sa);
+}
 
 void orc_bwt(const uint8_t *T, int n, uint8_t *bwt, int *orig, int *periodic) {
     if (periodic) *periodic = 1;
     *orig = 0;
     if (n == 0) return; /* S/BZip2DivSufSort.swift:3494-3495 */
+    if (g_tie_rule == 0) {
+        uint8_t *t2 = (uint8_t *)malloc((size_t)n + 1);
+        memcpy(t2, T, (size_t)n);
+        orc_bwt_divsufsort(t2, n, bwt, orig);
+        free(t2);
+        if (periodic) { /* k = n / (smallest period dividing n), via the KMP failure function */
+            int *f = (int *)malloc(sizeof(int) * ((size_t)n + 1));
+            f[0] = -1;
+            for (int i = 0, j = -1; i < n;) {
+                while (j >= 0 && T[i] != T[j]) j = f[j];
+                f[++i] = ++j;
+            }
+            int p = n - f[n];
+            *periodic = (n % p == 0) ? n / p : 1;
+            free(f);
+        }
+        return;
+    }
     if (n == 1) {       /* :3496-3499 */
         bwt[0] = T[0];
         return;
@@ -179,7 +223,7 @@ void orc_bwt(const uint8_t *T, int n, uint8_t *bwt, int *orig, int *periodic) {
     int o = rank[0];
     if (k > 1 && k < n) {
         /* tie rule for periodic blocks (DESIGN.md "orig on periodic blocks") */
-        if (g_tie_rule == 1) o += k - 1;
+        if (g_tie_rule == 2) o += k - 1;
     }
     if (k == n) o = 0; /* all-equal: S/BZip2DivSufSort.swift:3168-3174,3505 */
     *orig = o;
@@ -678,6 +722,7 @@ size_t orc_compress_mt(const uint8_t *in, size_t n, int level, uint8_t *out, siz
     uint64_t *starts = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)max_blocks);
     int nb = orc_split(in, n, level, starts, max_blocks);
     mt_job_t J;
+    g_sa_block_size = level * 100000; /* sizes tier 2's work array like the reference's bwtBlock */
     J.in = in; J.n = n; J.bs = level * 100000; J.starts = starts; J.n_blocks = nb; J.next = 0;
     pthread_mutex_init(&J.mu, NULL);
     J.bits = (uint8_t **)calloc((size_t)nb + 1, sizeof(uint8_t *));

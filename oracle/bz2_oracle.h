@@ -40,12 +40,25 @@ size_t orc_rle1_block(const uint8_t *in, size_t n_in, int block_size, uint8_t *b
                       int *block_len, uint8_t present[256], uint32_t *block_crc);
 
 /* S/BZip2DivSufSort.swift:3487-3506 contract: last column of sorted cyclic rotations and
- * the sorted position of rotation 0.  Tier 1 = prefix doubling (exact for every block that
- * is not a perfect power w^k).  For periodic blocks the k tied rotations are ordered by
- * bz2 tie rule `tie_rule`: *periodic is set to the period count k (1 if
- * aperiodic).  */
+ * the sorted position of rotation 0.  *periodic is set to the period count k (block == w^k;
+ * 1 if aperiodic).  The k rotations equal to rotation 0 are indistinguishable, so the origin
+ * pointer of a periodic block depends on the sorter; orc_set_tie_rule selects it:
+ *   0 (default)  tier 2: the reference's own sorter restated (divsufsort_restate.c)
+ *   1            tier 1: prefix doubling, first position of the class
+ *   2            tier 1: prefix doubling, last position of the class
+ * Tier 1 is an independent algorithm kept as a cross-check: same bytes always, same origin
+ * pointer on every aperiodic block. */
 void orc_bwt(const uint8_t *T, int n, uint8_t *bwt, int *orig, int *periodic);
 
+/* Tier 2: restatement of the reference's BZip2DivSufSort (divsufsort_restate.c).  T must have
+ * room for n + 1 bytes (T[n] := T[0]).  It is what orc_bwt uses under the default tie rule 0. */
+void orc_bwt_divsufsort(uint8_t *T, int n, uint8_t *bwt, int *orig);
+int orc_divsufsort_bwt(const uint8_t *T, int *sa_out, int n, int sa_len, int *trap);
+/* Declared block size (level * 100000) that sizes tier 2's zero-filled work array, as the
+ * reference's bwtBlock is sized (0 = smallest multiple of 100000 that holds n). */
+void orc_set_block_size(int block_size);
+/* Number of blocks so far on which the reference would have failed with an index error. */
+int orc_divsufsort_traps(void);
 /* Brute-force cross-check (n small): sorts rotations with memcmp on the doubled string. */
 void orc_bwt_bruteforce(const uint8_t *T, int n, uint8_t *bwt, int *orig_first, int *orig_last);
 
@@ -92,7 +105,7 @@ size_t orc_compress_mt(const uint8_t *in, size_t n, int level, uint8_t *out, siz
  * returns the number of blocks. */
 int orc_split(const uint8_t *in, size_t n, int level, uint64_t *starts, int max);
 
-/* Selects the tie rule for periodic blocks: 0 = class start (+0), see DESIGN.md */
+/* Selects the tie rule for periodic blocks (see orc_bwt). */
 void orc_set_tie_rule(int rule);
 
 #ifdef __cplusplus

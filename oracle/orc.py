@@ -19,7 +19,8 @@ MAX_TABLES = 6
 def build(force=False):
     if force or not os.path.exists(_SO) or (
         os.path.exists(os.path.join(_HERE, "bz2_oracle.c"))
-        and os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "bz2_oracle.c"))
+        and os.path.getmtime(_SO) < max(os.path.getmtime(os.path.join(_HERE, f))
+                                        for f in ("bz2_oracle.c", "divsufsort_restate.c", "bz2_oracle.h"))
     ):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
@@ -42,6 +43,8 @@ def lib():
                                      C.POINTER(C.c_int), C.c_void_p, C.POINTER(C.c_uint32)]
         L.orc_bwt.restype = None
         L.orc_bwt.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_bwt_divsufsort.restype = None
+        L.orc_bwt_divsufsort.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
         L.orc_bwt_bruteforce.restype = None
         L.orc_bwt_bruteforce.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int),
                                          C.POINTER(C.c_int)]
@@ -71,6 +74,10 @@ def lib():
         L.orc_compress_bound.argtypes = [C.c_size_t]
         L.orc_split.restype = C.c_int
         L.orc_split.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_int]
+        L.orc_set_block_size.restype = None
+        L.orc_set_block_size.argtypes = [C.c_int]
+        L.orc_divsufsort_traps.restype = C.c_int
+        L.orc_divsufsort_traps.argtypes = []
         L.orc_set_tie_rule.restype = None
         L.orc_set_tie_rule.argtypes = [C.c_int]
         _lib = L
@@ -116,6 +123,17 @@ def bwt(block):
     per = C.c_int(0)
     lib().orc_bwt(_ptr(a), a.size, _ptr(out), C.byref(orig), C.byref(per))
     return out[: a.size], orig.value, per.value
+
+
+def bwt_divsufsort(block):
+    """Tier 2 (restated reference sorter) -> (bwt bytes, orig)"""
+    a = _u8(block)
+    t = np.zeros(a.size + 1, dtype=np.uint8)
+    t[: a.size] = a
+    out = np.zeros(max(a.size, 1), dtype=np.uint8)
+    orig = C.c_int(0)
+    lib().orc_bwt_divsufsort(_ptr(t), a.size, _ptr(out), C.byref(orig))
+    return out[: a.size], orig.value
 
 
 def bwt_bruteforce(block):
@@ -202,6 +220,16 @@ def split(data, level=9):
     starts = np.zeros(mx, dtype=np.uint64)
     nb = lib().orc_split(_ptr(a), a.size, level, _ptr(starts), mx)
     return starts[:nb].copy()
+
+
+def set_block_size(block_size):
+    """Declared block size (level * 100000) sizing tier 2's work array; 0 = derive from n."""
+    lib().orc_set_block_size(block_size)
+
+
+def divsufsort_traps():
+    """Blocks so far on which the reference's sorter would have indexed past its array."""
+    return lib().orc_divsufsort_traps()
 
 
 def set_tie_rule(rule):

@@ -149,6 +149,55 @@ def test_adversarial(ctx, orc):
             assert bz2.decompress(got) == d.tobytes()
 
 
+def _periodic_inputs():
+    rng = np.random.default_rng(77)
+    return {
+        "zeros_2M": np.zeros(2_000_000, dtype=np.uint8),             # RLE1 -> (0,0,0,0,251)^k blocks
+        "ab": np.tile(np.frombuffer(b"ab", dtype=np.uint8), 1_000_000),   # (ab)^449998 per -9 block
+        "w5": np.tile(np.array([0, 0, 1, 2, 0], dtype=np.uint8), 9000),
+        "w8": np.tile(np.array([0, 2, 2, 1, 0, 0, 2, 2], dtype=np.uint8), 12500),
+        "w31": np.tile(rng.integers(0, 4, 31, dtype=np.uint8), 3200),
+        "w1000": np.tile(rng.integers(0, 256, 1000, dtype=np.uint8), 99),
+        "w33333^3": np.tile(rng.integers(0, 256, 33333, dtype=np.uint8), 3),
+        "abc33": np.tile(np.frombuffer(b"abc", dtype=np.uint8), 33),
+        "same3": np.full(3, 65, dtype=np.uint8),
+        "zeros4": np.zeros(4, dtype=np.uint8),                       # RLE1 -> five zero bytes
+    }
+
+
+def test_periodic_blocks_origin_pointer(ctx, orc):
+    """Blocks that are perfect powers w^k: the origin pointer follows the reference's sorter
+    (k2_tie.hip replays it on the device); whole streams equal the oracle's tier 2."""
+    seen = 0
+    for name, d in _periodic_inputs().items():
+        for level in (1, 9):
+            want, _ = orc.compress(d, level)
+            got = ctx.compress(d, level)
+            seen += ctx.last_stats()["periodic_blocks"]
+            assert got == want, (name, level)
+            assert bz2.decompress(got) == d.tobytes()
+    assert seen >= 8  # the tie kernel really ran
+
+
+def test_periodic_blocks_fast_rules(orc):
+    """BZ2HIP_TIE_FIRST / _LAST skip the replay; streams equal the oracle's tier 1 under the
+    same rule and still decode."""
+    from bzip2_amd import Context
+    try:
+        for rule in (1, 2):
+            orc.set_tie_rule(rule)
+            c = Context(tie_rule=rule)
+            for name in ("ab", "w31", "zeros_2M"):
+                d = _periodic_inputs()[name]
+                want, _ = orc.compress(d, 9)
+                got = c.compress(d, 9)
+                assert got == want, (name, rule)
+                assert bz2.decompress(got) == d.tobytes()
+            c.close()
+    finally:
+        orc.set_tie_rule(0)
+
+
 def test_text900k_config2(ctx, orc):
     # BASELINE config 2: one full 900k block, byte-exact vs the oracle
     d = corpus.text900k()

@@ -126,6 +126,44 @@ def test_bwt_periodic(orc):
         assert first <= orig <= last or per == len(c)
 
 
+def test_bwt_tiers_agree(orc):
+    """Tier 2 (restated reference sorter, the default) vs tier 1 (prefix doubling): same bytes
+    always; same origin pointer on aperiodic blocks; inside rotation 0's class on periodic ones."""
+    rng = np.random.default_rng(12)
+    cases = [corpus.segment(kind, 120000, 40 + i) for i, kind in
+             enumerate(("text", "random", "runs", "periodic", "binary", "markov", "dna"))]
+    cases += [v for v in corpus.adversarial(60000).values()]
+    cases += [np.tile(rng.integers(0, a, w, dtype=np.uint8), k)
+              for (a, w, k) in ((2, 2, 5000), (3, 5, 900), (256, 1000, 90), (4, 31, 2900), (256, 30000, 3))]
+    cases += [rng.integers(0, a, n, dtype=np.uint8) for a in (1, 2, 4) for n in (1, 2, 3, 5, 8, 9, 1025)]
+    try:
+        for c in cases:
+            orc.set_tie_rule(0)
+            b2, o2, k2 = orc.bwt(c)
+            orc.set_tie_rule(1)
+            b1, o1, k1 = orc.bwt(c)
+            assert np.array_equal(b1, b2) and k1 == k2
+            if k1 == 1 or k1 == len(c):
+                assert o1 == o2
+            else:
+                assert o1 <= o2 < o1 + k1
+    finally:
+        orc.set_tie_rule(0)
+
+
+def test_divsufsort_small_exhaustive(orc):
+    # every string over {0,1,2} up to length 7, and over {0,1} up to length 12
+    import itertools
+    for alpha, maxn in ((3, 7), (2, 12)):
+        for n in range(1, maxn + 1):
+            for tup in itertools.product(range(alpha), repeat=n):
+                c = bytes(tup)
+                bw, orig = orc.bwt_divsufsort(c)
+                bf, first, last = orc.bwt_bruteforce(c)
+                assert np.array_equal(bw, bf), c
+                assert first <= orig <= last or len(set(tup)) == 1, c
+
+
 def test_mtf_rle2_small(orc):
     # BWT "aaab" with symbols {a, b}: positions 0,0,0,1 -> run of 3 zeros = RUNA RUNA(?)
     pres = np.zeros(256, dtype=np.uint8)
