@@ -745,7 +745,9 @@ __global__ __launch_bounds__(RT_THREADS, 4) void k2_ssort(const u64 *slA, const 
         __syncthreads();
         for (int q = cnt + threadIdx.x; q < N; q += RT_THREADS) buf[q] = ~0ull;
         __syncthreads();
+#ifndef EXP_NOSORT
         bitonic_sort_lds(buf, N);
+#endif
     } else {
         // FINAL: order inside groups is irrelevant; keep the span in place at buf[0..cnt)
         int N = 256;
