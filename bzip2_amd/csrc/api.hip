@@ -54,6 +54,10 @@ static void ensure_batch(bz2hip_ctx *c, int level, int nb_needed) {
     N.tilehist = dalloc<u32>(c, nb * N.TPB * 256);
     N.digitbase = dalloc<u32>(c, nb * 256);
     N.tileagg = dalloc<u32>(c, nb * N.TPB * 4);
+    N.pvote = dalloc<u32>(c, nb * 8192 * 2);
+    N.cand = dalloc<u32>(c, nb * 2);
+    N.vagg = dalloc<u32>(c, nb * 2 * N.TPB * 2);
+    N.runs = dalloc<u32>(c, nb * 68);
     N.nheads = dalloc<u32>(c, nb);
     N.active = dalloc<u32>(c, nb);
     N.rounds = dalloc<u32>(c, nb);

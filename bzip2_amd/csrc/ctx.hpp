@@ -43,6 +43,10 @@ struct Batch {
     u32 *tilehist = nullptr;  // [NB][TPB][256]
     u32 *digitbase = nullptr; // [NB][256]
     u32 *tileagg = nullptr;   // [NB][TPB][4]
+    u32 *pvote = nullptr;     // [NB][8192][2] distance votes {count, distance} (long-repeat rule)
+    u32 *cand = nullptr;      // [NB][2] distances kept
+    u32 *vagg = nullptr;      // [NB][2][TPB][2] per-tile min/max violation position
+    u32 *runs = nullptr;      // [NB][68] regions {p, a, e, dir}
     u32 *nheads = nullptr;    // [NB]
     u32 *active = nullptr;    // [NB]
     u32 *rounds = nullptr;    // [NB]

@@ -605,6 +605,123 @@ __device__ __forceinline__ void bitonic_sort_lds(u64 *buf, int N) {
     }
 }
 
+#define GF_NONUNI 1u
+#define GF_ASC 2u
+#define GF_DESC 4u
+#define GF_NONAP 8u
+#define GF_RUN 16u
+
+// ------------------------------------------------------------------ long repeats at a fixed distance
+// Doubling needs log2(L/h) rounds to tell apart suffixes i and i+p that agree for L symbols (a
+// region of period p, or a second copy of the same data p bytes later): nothing splits until h
+// reaches L.  T itself settles such pairs at once: with V = {y : T[y] != T[y-p]}, a maximal gap
+// (v1, v2) of V is a region [a, e) = [v1+1-p, v2) on which T[y] = T[y-p], and for every pair
+// (i, i+p) with a <= i, i+p <= e the suffixes first differ at e: suffix i reads T[e-p], suffix
+// i+p reads T[e].  The first S-round votes for the distances p seen between group neighbours,
+// k2_pick keeps the two most frequent per block, k2_viol/k2_runs list their long regions, and
+// k2_ssort then finishes any group whose index-ordered members are all such pairs (run rule).
+#define VT 8192           // vote slots per block
+#define NCAND 2           // distances kept per block
+#define MAXRUNS 8         // regions kept per distance
+#define MINRUN 4096u      // shortest gap of V worth recording (also > tile, so a tile holds no whole gap)
+#define RUNS_STRIDE (4 + 4 * NCAND * MAXRUNS)
+#define VSLOT(d) (((d) * 2654435761u) >> 19)
+
+__global__ __launch_bounds__(256) void k2_pick(const u32 *__restrict__ pvote,
+                                               const u32 *__restrict__ nArr, u32 *__restrict__ cand,
+                                               u32 *__restrict__ runs, u32 nb) {
+    const u32 b = blockIdx.x;
+    __shared__ u32 sm[8];
+    const u32 *pv = pvote + (size_t)b * VT * 2;
+    const u32 n = nArr[b];
+    u32 first = 0;
+    for (int pass = 0; pass < NCAND; pass++) {
+        u32 best = 0;
+        for (u32 sl = threadIdx.x; sl < VT; sl += 256) {
+            u32 cnt = pv[2 * sl];
+            if (cnt >= 8 && !(pass == 1 && sl == (first & (VT - 1)) && first))
+                best = max(best, (min(cnt, 0x7FFFFu) << 13) | sl);
+        }
+        best = block_reduce_max<256>(best, sm);
+        if (pass == 0) first = best;
+        if (threadIdx.x == 0) {
+            u32 pp = best ? pv[2 * (best & (VT - 1)) + 1] : 0;
+            if (pp == 0 || pp >= n) pp = 0;
+            cand[b * NCAND + pass] = pp;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) runs[(size_t)b * RUNS_STRIDE] = 0;
+}
+
+// per tile of y in [p, n + p): smallest and largest y with T[y mod n] != T[y - p]
+__global__ __launch_bounds__(256) void k2_viol(const u8 *__restrict__ T, const u32 *__restrict__ nArr,
+                                               const u32 *__restrict__ cand, u32 *__restrict__ vagg,
+                                               u32 S, u32 TPB) {
+    const u32 b = blockIdx.z, cidx = blockIdx.y, t = blockIdx.x;
+    const u32 p = cand[b * NCAND + cidx];
+    if (!p) return;
+    const u32 n = nArr[b];
+    const u32 base = t * RTILE;
+    if (base >= n) return;
+    __shared__ u32 sm[8];
+    const u8 *Tb = T + (size_t)b * S;
+    u32 lo = 0xFFFFFFFFu, hi = 0;
+#pragma unroll 4
+    for (int k = 0; k < RT_ITEMS; k++) {
+        u32 off = base + k * 256 + threadIdx.x;
+        if (off < n) {
+            u32 y = off + p; // y - p = off
+            u32 ym = y >= n ? y - n : y;
+            if (Tb[ym] != Tb[off]) {
+                lo = min(lo, y);
+                hi = max(hi, y);
+            }
+        }
+    }
+    hi = block_reduce_max<256>(hi, sm);
+    lo = ~block_reduce_max<256>(~lo, sm);
+    if (threadIdx.x == 0) {
+        u32 *o = vagg + (((size_t)b * NCAND + cidx) * TPB + t) * 2;
+        o[0] = lo;
+        o[1] = hi;
+    }
+}
+
+__global__ void k2_runs(const u8 *__restrict__ T, const u32 *__restrict__ nArr,
+                        const u32 *__restrict__ cand, const u32 *__restrict__ vagg,
+                        u32 *__restrict__ runs, u32 S, u32 TPB, u32 nb) {
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const u32 n = nArr[b];
+    const u8 *Tb = T + (size_t)b * S;
+    u32 *R = runs + (size_t)b * RUNS_STRIDE;
+    u32 cnt = 0;
+    for (u32 cidx = 0; cidx < NCAND; cidx++) {
+        const u32 p = cand[b * NCAND + cidx];
+        if (!p) continue;
+        const u32 tiles = (n + RTILE - 1) / RTILE;
+        u32 lastv = p - 1, kept = 0; // y < p cannot be compared: the block start bounds the first region
+        for (u32 t = 0; t < tiles && kept < MAXRUNS; t++) {
+            const u32 *a = vagg + (((size_t)b * NCAND + cidx) * TPB + t) * 2;
+            const u32 lo = a[0], hi = a[1];
+            if (lo == 0xFFFFFFFFu) continue;
+            if (lo - lastv - 1 >= MINRUN) {
+                const u32 e = lo, em = e >= n ? e - n : e;
+                u32 *o = R + 4 + 4 * cnt;
+                o[0] = p;
+                o[1] = lastv + 1 - p;
+                o[2] = e;
+                o[3] = (Tb[e - p] < Tb[em]) ? GF_ASC : GF_DESC;
+                cnt++;
+                kept++;
+            }
+            lastv = hi;
+        }
+    }
+    R[0] = cnt;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(RT_THREADS, 4) void k2_ssort(const u64 *slA, const u64 *slB,
                                                        u64 *slAo, u64 *slBo,
@@ -615,6 +732,9 @@ __global__ __launch_bounds__(RT_THREADS, 4) void k2_ssort(const u64 *slA, const 
                                                        const u8 *__restrict__ T, u8 *__restrict__ bwt,
                                                        const u32 *__restrict__ nArr,
                                                        u32 *__restrict__ mSn, u32 *__restrict__ leftg,
+                                                       const u32 *__restrict__ huse,
+                                                       u32 *__restrict__ pvote,
+                                                       const u32 *__restrict__ runs,
                                                        u32 S, u32 gtiles, u32 gnb) {
     XCD_MAP(gtiles, gnb)
     const u32 b = bz_b;
@@ -625,7 +745,12 @@ __global__ __launch_bounds__(RT_THREADS, 4) void k2_ssort(const u64 *slA, const 
     __shared__ u64 buf[RTILE];
     __shared__ int sm[16];
     __shared__ int s_start, s_end;
-    __shared__ u8 gflag[RTILE];
+    __shared__ __attribute__((aligned(16))) u8 gflag[RTILE];
+    __shared__ u32 s_runs[RUNS_STRIDE];
+    if (MODE == MODE_NORMAL) {
+        if (threadIdx.x < RUNS_STRIDE)
+            s_runs[threadIdx.x] = runs ? runs[(size_t)b * RUNS_STRIDE + threadIdx.x] : 0u;
+    }
     const u64 *in = (par[b] ? slB : slA) + (size_t)b * S;
     u64 *out = (par[b] ? slAo : slBo) + (size_t)b * S;
     const int loaded = (int)min((u32)RTILE, m - t0);
@@ -660,15 +785,26 @@ __global__ __launch_bounds__(RT_THREADS, 4) void k2_ssort(const u64 *slA, const 
     if (MODE == MODE_NORMAL) {
         // Groups whose k2 is the same for every member cannot split this round: they pass
         // through untouched (rank and grp unchanged).  Only the others are compacted and sorted.
+        //
+        // Arithmetic-progression rule.  Inside a group the list is in index order.  If the indices
+        // are i0, i0+p, i0+2p, ... with p <= h (h = depth the ranks stand for), the h-symbol
+        // prefixes they share overlap, so T has period p on [i0, ic + h) and every consecutive pair
+        // (i, i+p) first differs at the same position e = first y >= ic + h with T[y] != T[y-p]:
+        // suffix i reads T[e-p] there, suffix i+p reads T[e].  The group's order is therefore
+        // monotone in the index, and one pair with different k2 gives the direction.  Such a group is
+        // finished in this round whatever its length (k2 := slot, or its complement).
         u64 ev[16];
         u64 hm[16];
         u64 dm[16];
+        u32 fl[16]; // per element: GF_* bits it contributes to its group
         int lastHead = NOHEAD;
+        const u32 hcur = huse[b];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const int rb = w * 1024 + k * 64;
             const int q = rb + lane;
             bool head = false, diff = false;
+            u32 f = 0, vd = 0;
             u64 e = ~0ull;
             if (q >= start && q < end) {
                 e = buf[q];
@@ -676,13 +812,51 @@ __global__ __launch_bounds__(RT_THREADS, 4) void k2_ssort(const u64 *slA, const 
                 else {
                     u64 ep = buf[q - 1];
                     head = (e >> 40) != (ep >> 40);
-                    diff = !head && ((e >> KEY_SHIFT) != (ep >> KEY_SHIFT));
+                    if (!head) {
+                        const u32 k2 = (u32)(e >> KEY_SHIFT) & 0xFFFFFu, k2p = (u32)(ep >> KEY_SHIFT) & 0xFFFFFu;
+                        diff = k2 != k2p;
+                        if (diff) f |= (k2 > k2p) ? (GF_NONUNI | GF_ASC) : (GF_NONUNI | GF_DESC);
+                        const u32 i1 = (u32)(e & E_IMASK), i0 = (u32)(ep & E_IMASK);
+                        const u32 d = i1 - i0;
+                        if (i1 <= i0) f |= GF_NONAP;
+                        else if (d > hcur) {
+                            // run rule: the pair must lie in a recorded region of distance d
+                            u32 ok = 0;
+                            const u32 nr = s_runs[0];
+                            for (u32 r = 0; r < nr; r++) {
+                                const u32 *R = s_runs + 4 + 4 * r;
+                                if (R[0] == d && i0 >= R[1] && i1 <= R[2]) ok = R[3];
+                            }
+                            f |= ok ? (GF_RUN | ok) : GF_NONAP;
+                            vd = d;
+                        }
+                        if (q - 2 >= start) {
+                            u64 epp = buf[q - 2];
+                            if ((epp >> 40) == (e >> 40) && i0 - (u32)(epp & E_IMASK) != d) f |= GF_NONAP;
+                        }
+                    }
+                }
+            }
+            if (pvote && k == 0 && w == 0) {
+                // votes (first 64 slots of the window only: global atomics are dear): neighbouring
+                // lanes of one group carry the same distance; one atomic per such stretch
+                const u32 vprev = __shfl_up(vd, 1, 64);
+                const bool vote = vd != 0;
+                const bool rh = vote && (lane == 0 || vprev != vd);
+                const u64 hm_ = __ballot(rh), vm_ = __ballot(vote);
+                if (rh) {
+                    const u64 above = (lane == 63) ? 0ull : ((hm_ | ~vm_) & (~0ull << (lane + 1)));
+                    const u32 cnt = (above ? (u32)__ffsll((unsigned long long)above) - 1u : 64u) - (u32)lane;
+                    u32 *pv = pvote + ((size_t)b * VT + VSLOT(vd)) * 2;
+                    atomicAdd(pv, cnt);
+                    pv[1] = vd;
                 }
             }
             ev[k] = e;
+            fl[k] = f;
             u64 a = __ballot(head);
             hm[k] = a;
-            dm[k] = __ballot(diff);
+            dm[k] = __ballot(f != 0);
             if (a) lastHead = rb + 63 - __clzll((unsigned long long)a);
         }
         for (int q = threadIdx.x; q < RTILE / 4; q += RT_THREADS) ((u32 *)gflag)[q] = 0;
@@ -699,7 +873,8 @@ __global__ __launch_bounds__(RT_THREADS, 4) void k2_ssort(const u64 *slA, const 
             u64 mo = hm[k] & le;
             ohi[k] = mo ? rb + 63 - __clzll((unsigned long long)mo) : cO;
             if (hm[k]) cO = rb + 63 - __clzll((unsigned long long)hm[k]);
-            if ((dm[k] >> lane) & 1ull) gflag[ohi[k]] = 1;
+            if ((dm[k] >> lane) & 1ull)
+                atomicOr((u32 *)gflag + (ohi[k] >> 2), fl[k] << ((ohi[k] & 3) * 8));
         }
         __syncthreads();
         // counts
@@ -709,7 +884,16 @@ __global__ __launch_bounds__(RT_THREADS, 4) void k2_ssort(const u64 *slA, const 
         for (int k = 0; k < 16; k++) {
             const int q = w * 1024 + k * 64 + lane;
             bool in_span = (q >= start && q < end);
-            bool nonuni = in_span && gflag[ohi[k]] != 0;
+            const u32 gf = in_span ? gflag[ohi[k]] : 0u;
+            bool nonuni = (gf & GF_NONUNI) != 0;
+            const bool onedir = (gf & (GF_ASC | GF_DESC)) == GF_ASC || (gf & (GF_ASC | GF_DESC)) == GF_DESC;
+            if ((gf & (GF_NONUNI | GF_RUN)) && !(gf & GF_NONAP) && onedir) {
+                nonuni = true; // finished this round even if its k2 is still uniform
+                // arithmetic progression: final order = index order (ASC) or its reverse (DESC)
+                const u32 slot = (u32)(q - ohi[k]);
+                const u32 code = (gf & GF_ASC) ? slot : (0xFFFFFu - slot);
+                ev[k] = (ev[k] & ~(0xFFFFFull << KEY_SHIFT)) | ((u64)code << KEY_SHIFT);
+            }
             nmask[k] = __ballot(nonuni);
             umask[k] = __ballot(in_span && !nonuni);
             cN += __popcll(nmask[k]);
@@ -890,6 +1074,8 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
     radix_sort5(c, nb, maxn, B.n, B.keyA, B.keyB); // result in keyB
     lrerank<MODE_ROUND0>(c, nb, maxn, B.n, ST_ACTIVE, B.keyB, B.keyA);
     bool first = true;
+    int rnd = 0; // S-rounds launched so far
+    HIPCHK(hipMemsetAsync(B.pvote, 0, (size_t)nb * VT * 2 * sizeof(u32), c->stream));
     u32 finS = 0, finL = 0;
     bool anyfin = false;
     for (;;) {
@@ -936,13 +1122,24 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
             ProfScope ps(c, P_BWT_SSORT);
             k2_ssort<MODE_NORMAL><<<xcd_grid((maxS + SC - 1) / SC, nb), RT_THREADS, 0, c->stream>>>(
                 B.slA, B.slB, B.slA, B.slB, B.par, B.mS, B.state, ST_ACTIVE, B.rank, B.T, B.bwt, B.n,
-                B.mSn, B.leftg, B.S, (maxS + SC - 1) / SC, nbarg(nb, 2));
+                B.mSn, B.leftg, B.huse, rnd == 0 ? B.pvote : (u32 *)nullptr,
+                rnd == 0 ? (const u32 *)nullptr : B.runs, B.S, (maxS + SC - 1) / SC, nbarg(nb, 2));
+            KCHECK();
+            if (rnd == 0) {
+                k2_pick<<<nb, 256, 0, c->stream>>>(B.pvote, B.n, B.cand, B.runs, nb);
+                KCHECK();
+                k2_viol<<<dim3(tiles, NCAND, nb), 256, 0, c->stream>>>(B.T, B.n, B.cand, B.vagg, B.S, B.TPB);
+                KCHECK();
+                k2_runs<<<cb, 256, 0, c->stream>>>(B.T, B.n, B.cand, B.vagg, B.runs, B.S, B.TPB, nb);
+                KCHECK();
+            }
             KCHECK();
         }
         if (maxL) {
             radix_sort5(c, nb, maxL, B.mL, B.keyA, B.keyB);
             lrerank<MODE_NORMAL>(c, nb, maxL, B.mL, ST_ACTIVE, B.keyB, B.keyA);
         }
+        if (maxS) rnd++;
     }
     if (anyfin) {
         // periodic blocks: flush the k-fold ties in list order
@@ -950,7 +1147,8 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
             ProfScope ps(c, P_BWT_SSORT);
             k2_ssort<MODE_FINAL><<<xcd_grid((finS + SC - 1) / SC, nb), RT_THREADS, 0, c->stream>>>(
                 B.slA, B.slB, B.slA, B.slB, B.par, B.mS, B.state, ST_FIN, B.rank, B.T, B.bwt, B.n,
-                B.mSn, B.leftg, B.S, (finS + SC - 1) / SC, nbarg(nb, 2));
+                B.mSn, B.leftg, B.huse, (u32 *)nullptr, (const u32 *)nullptr, B.S, (finS + SC - 1) / SC,
+                nbarg(nb, 2));
             KCHECK();
         }
         if (finL) lrerank<MODE_FINAL>(c, nb, finL, B.mL, ST_FIN, B.keyA, B.keyB);
