@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-sample-mib", type=int, default=48)
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--profile-all", action="store_true",
+                    help="HIP events around every kernel class (adds ~2 ms per step of event overhead)")
     args = ap.parse_args()
 
     import numpy as np
@@ -59,7 +61,7 @@ def main():
                     f"{world * args.segments} MiB total")
     n_in = int(data.size)
     d_in = torch.from_numpy(data).to(dev)
-    ctx = Context(device=local_rank, max_batch_blocks=args.batch, profile=not args.no_profile)
+    ctx = Context(device=local_rank, max_batch_blocks=args.batch, profile=0 if args.no_profile else (2 if args.profile_all else 1))
     L = ctx.L
     cap = L.bz2hip_compress_bound(n_in)
     d_out = torch.empty(cap + 64, dtype=torch.uint8, device=dev)
@@ -145,7 +147,7 @@ def main():
                 for k in KERNEL}
             bwt_cls = ["bwt_init", "radix_hist", "radix_scan", "radix_scatter", "bwt_keys", "bwt_ssort",
                        "bwt_rerank", "bwt_emit", "bwt_tie"]
-            t_bwt = sum(prof[k]["ms"] for k in bwt_cls) * 1e-3 / args.steps
+            t_bwt = sum(prof[k]["ms"] for k in bwt_cls) * 1e-3 / args.steps if args.profile_all else 0.0
             n_rle = stats["rle_bytes"]
             # B_bwt = 15 n + 140 R n, with our depth-8 first sort counted as R0 = 3
             b_bwt = 15.0 * n_rle + 140.0 * (stats["n_times_rounds"] + 3.0 * n_rle)

@@ -134,7 +134,7 @@ class Context:
     def __init__(self, device=-1, max_batch_blocks=0, tie_rule=0, profile=False):
         self.L = load()
         self.h = C.c_void_p()
-        o = Opts(device, max_batch_blocks, tie_rule, 1 if profile else 0)
+        o = Opts(device, max_batch_blocks, tie_rule, int(profile))
         rc = self.L.bz2hip_create(C.byref(self.h), C.byref(o))
         if rc != OK:
             raise BZ2HipError(rc, "bz2hip_create failed: " +

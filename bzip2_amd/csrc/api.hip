@@ -199,6 +199,7 @@ extern "C" int bz2hip_create(bz2hip_ctx **out, const bz2hip_opts *opts) {
     if (dev >= ndev) { delete c; return BZ2HIP_E_PARAM; }
     c->device = dev;
     c->profile = c->opts.profile != 0;
+    c->profile_level = c->opts.profile;
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
         g_create_err = "hipSetDevice/hipStreamCreate failed";
         delete c;

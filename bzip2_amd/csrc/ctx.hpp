@@ -104,6 +104,7 @@ struct bz2hip_ctx {
     u8 *h_out = nullptr; size_t h_out_cap = 0;
     // profiling
     bool profile = false;
+    int profile_level = 0;   // 1 = bandwidth kernels only (few events), 2 = every kernel class
     std::vector<ProfRec> prof_pending;
     std::vector<hipEvent_t> ev_pool;
     double prof_ms[P_COUNT] = {0};
@@ -154,8 +155,12 @@ struct ProfScope {
     bz2hip_ctx *c;
     int cls;
     hipEvent_t e0 = nullptr;
+    static bool heavy(int k) {
+        return k == P_RADIX_HIST || k == P_RADIX_SCATTER || k == P_BWT_KEYS || k == P_BWT_SSORT ||
+               k == P_MTF_REPLAY || k == P_BWT_RERANK || k == P_BWT_TIE;
+    }
     ProfScope(bz2hip_ctx *ctx, int k, double alg_bytes = 0) : c(ctx), cls(k) {
-        if (c->profile) {
+        if (c->profile && (c->profile_level >= 2 || heavy(k))) {
             e0 = c->get_event();
             HIPCHK(hipEventRecord(e0, c->stream));
             c->prof_bytes[cls] += alg_bytes;

@@ -51,14 +51,14 @@ enum { CLS_NONE = 0, CLS_SINGLE = 1, CLS_SMALL = 2, CLS_LKEEP = 3 };
 // ------------------------------------------------------------------ per-block control
 __global__ void k2_reset(const u32 *__restrict__ nArr, const u32 *__restrict__ present,
                          u32 *mS, u32 *mL, u32 *mSn, u32 *mLn, u32 *hcur, u32 *huse, u32 *state,
-                         u32 *par, u32 *rounds, u32 *leftg, u32 *periodic, u32 *ctl, u32 nb) {
+                         u32 *par, u32 *rounds, u32 *leftg, u32 *periodic, u32 *ctl, u32 nb, u32 r0bits) {
     u32 b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
     u32 uniq = 0;
     for (int q = 0; q < 8; q++) uniq += __popc(present[b * 8 + q]);
     u32 bps = 1;
     while ((1u << bps) < uniq) bps++;
-    u32 d0 = 40 / bps;
+    u32 d0 = r0bits / bps;
     mS[b] = 0; mL[b] = 0; mSn[b] = 0; mLn[b] = 0;
     hcur[b] = d0; huse[b] = d0;
     state[b] = nArr[b] > 0 ? ST_ACTIVE : ST_DONE;
@@ -99,7 +99,7 @@ __global__ void k2_ctl(const u32 *__restrict__ nArr, u32 *mS, u32 *mL, u32 *mSn,
 __global__ __launch_bounds__(RT_THREADS) void k2_init_keys(const u8 *__restrict__ T,
                                                            const u32 *__restrict__ nArr,
                                                            const u32 *__restrict__ present,
-                                                           u64 *__restrict__ key, u32 S, u32 gtiles, u32 gnb) {
+                                                           u64 *__restrict__ key, u32 S, u32 gtiles, u32 gnb, u32 r0bits) {
     XCD_MAP(gtiles, gnb)
     const u32 b = bz_b;
     const u32 n = nArr[b];
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(RT_THREADS) void k2_init_keys(const u8 *__restrict_
     __syncthreads();
     if (base >= n) return;
     const u32 bps = s_bps;
-    const u32 d0 = 40 / bps;
+    const u32 d0 = r0bits / bps;
     const u8 *t = T + (size_t)b * S;
     for (int k = 0; k < RT_ITEMS; k++) {
         u32 i = base + k * RT_THREADS + threadIdx.x;
@@ -1005,14 +1005,16 @@ void run_present(bz2hip_ctx *c, int nb, u32 maxn) {
 // ------------------------------------------------------------------ driver
 // bit set = plain (x-fastest) mapping for that kernel family; default: S-sort only
 static u32 g_plain_mask = 2;
+static u32 g_r0bits = 40; // key bits of the first sort (multiple of 8)
 static inline u32 nbarg(u32 nb, u32 bit) { return (g_plain_mask & bit) ? (nb | 0x80000000u) : nb; }
 
-static void radix_sort5(bz2hip_ctx *c, int nb, u32 maxcnt, const u32 *cntArr, u64 *a, u64 *bbuf) {
+static void radix_sort5(bz2hip_ctx *c, int nb, u32 maxcnt, const u32 *cntArr, u64 *a, u64 *bbuf,
+                        int passes = 5) {
     Batch &B = c->batch;
     const u32 tiles = (maxcnt + RTILE - 1) / RTILE;
     dim3 grid(tiles, nb);
     u64 *kin = a, *kout = bbuf;
-    for (int p = 0; p < 5; p++) {
+    for (int p = 0; p < passes; p++) {
         int shift = KEY_SHIFT + 8 * p;
         {
             ProfScope ps(c, P_RADIX_HIST);
@@ -1059,19 +1061,24 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
     Batch &B = c->batch;
     if (nb == 0 || maxn == 0) return;
     if (const char *pm = getenv("BZ2HIP_PLAIN")) g_plain_mask = (u32)atoi(pm);
+    if (const char *pm = getenv("BZ2HIP_R0BITS")) g_r0bits = (u32)atoi(pm);
     const u32 tiles = (maxn + RTILE - 1) / RTILE;
     const int cb = (nb + 255) / 256;
     HIPCHK(hipMemsetAsync(B.ctl, 0, 16 * sizeof(u32), c->stream));
     k2_reset<<<cb, 256, 0, c->stream>>>(B.n, B.present, B.mS, B.mL, B.mSn, B.mLn, B.hcur, B.huse,
-                                        B.state, B.par, B.rounds, B.leftg, B.periodic, B.ctl, nb);
+                                        B.state, B.par, B.rounds, B.leftg, B.periodic, B.ctl, nb, g_r0bits);
     KCHECK();
     {
         ProfScope ps(c, P_BWT_INIT);
-        k2_init_keys<<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(B.T, B.n, B.present, B.keyA, B.S,
-                                                                        tiles, nb);
+        k2_init_keys<<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(B.T, B.n, B.present, (g_r0bits / 8) & 1 ? B.keyA : B.keyB,
+                                                                        B.S, tiles, nb, g_r0bits);
         KCHECK();
     }
-    radix_sort5(c, nb, maxn, B.n, B.keyA, B.keyB); // result in keyB
+    const int r0p = (int)g_r0bits / 8;
+    // the sorted keys must end in keyB (the L-list is rebuilt into keyA): start in keyB when the
+    // pass count is even
+    if (r0p & 1) radix_sort5(c, nb, maxn, B.n, B.keyA, B.keyB, r0p);
+    else radix_sort5(c, nb, maxn, B.n, B.keyB, B.keyA, r0p);
     lrerank<MODE_ROUND0>(c, nb, maxn, B.n, ST_ACTIVE, B.keyB, B.keyA);
     bool first = true;
     int rnd = 0; // S-rounds launched so far
@@ -1089,10 +1096,10 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
         HIPCHK(hipStreamSynchronize(c->stream));
         if (first) {
             if (c->profile) {
-                c->prof_bytes[P_RADIX_SCATTER] += 5.0 * 16.0 * (double)hc[8];
-                c->prof_bytes[P_RADIX_HIST] += 5.0 * 8.0 * (double)hc[8];
+                c->prof_bytes[P_RADIX_SCATTER] += r0p * 16.0 * (double)hc[8];
+                c->prof_bytes[P_RADIX_HIST] += r0p * 8.0 * (double)hc[8];
             }
-            c->st_sorted_elems += (u64)hc[8] * 5;
+            c->st_sorted_elems += (u64)hc[8] * r0p;
             first = false;
         }
         anyfin = hc[4] != 0;

@@ -85,21 +85,22 @@ __global__ __launch_bounds__(256) void k3_mtf_chunks(const u8 *__restrict__ bwt,
         u32 j = rowbase + lane;
         u32 sym = (j < cend) ? smap[src[j]] : 0;
         u32 mypos = 0;
-        const int cnt = (int)min(64u, cend - rowbase);
-        for (int i = 0; i < cnt; i++) {
-            u32 s = __builtin_amdgcn_readlane(sym, i);
-            u32 pos = 0;
-            if (s != prev) {
-                pos = mtf_step(L, s);
-                prev = s;
-                if (!REPLAY) {
-                    if ((s >> 2) == (u32)lane) seen |= 1u << (s & 3);
-                }
+        // only run heads move the list (a repeated symbol is at position 0): visit set bits only
+        u32 left = (u32)__builtin_amdgcn_update_dpp((int)prev, (int)sym, 0x138, 0xf, 0xf, false);
+        u64 heads = __ballot(j < cend && sym != left);
+        while (heads) {
+            const int i = __ffsll((unsigned long long)heads) - 1;
+            heads &= heads - 1;
+            const u32 s = __builtin_amdgcn_readlane(sym, i);
+            const u32 pos = mtf_step(L, s);
+            if (!REPLAY) {
+                if ((s >> 2) == (u32)lane) seen |= 1u << (s & 3);
             }
             if (REPLAY) {
                 if (lane == i) mypos = pos;
             }
         }
+        prev = __builtin_amdgcn_readlane(sym, 63);
         if (REPLAY) {
             if (j < cend) mtfpos[(size_t)b * S + j] = (u8)mypos;
         }
