@@ -297,7 +297,12 @@ __global__ __launch_bounds__(RT_THREADS) void k2_keys(u64 *__restrict__ slA, u64
 // buf[0..cnt) holds a run of the (sorted) list in LDS; wave-row layout: wave w owns
 // [w*1024, w*1024+1024), 16 rows of 64.  Computes for every element the slot of its old / new
 // group head (tile-local, may be negative = before the tile) and of the next new head.
-template <int MODE>
+// LDS index swizzle of the S-sort window: lets a thread own 16 consecutive elements (register
+// stages of the bitonic network) without every lane hitting the same banks
+__device__ __forceinline__ int SZ(int i) { return i ^ ((i >> 4) & 15); }
+#define BUFX(i) buf[SWZ ? SZ(i) : (i)]
+
+template <int MODE, bool SWZ = false>
 __device__ __forceinline__ void tile_classify(const u64 *buf, int cnt, u64 prevE, bool has_prev,
                                               int carryOld, int carryNew, bool end_head,
                                               int *sm /* 12 ints */, int (&cls)[16],
@@ -312,7 +317,7 @@ __device__ __forceinline__ void tile_classify(const u64 *buf, int cnt, u64 prevE
         const int idx = rb + lane;
         bool nh = false, oh = false;
         if (idx < cnt) {
-            u64 e = buf[idx];
+            u64 e = BUFX(idx);
             if (idx == 0) {
                 if (!has_prev) {
                     nh = true;
@@ -322,7 +327,7 @@ __device__ __forceinline__ void tile_classify(const u64 *buf, int cnt, u64 prevE
                     oh = (MODE == MODE_ROUND0) ? false : ((e >> 40) != (prevE >> 40));
                 }
             } else {
-                u64 ep = buf[idx - 1];
+                u64 ep = BUFX(idx - 1);
                 nh = (e >> KEY_SHIFT) != (ep >> KEY_SHIFT);
                 oh = (MODE == MODE_ROUND0) ? false : ((e >> 40) != (ep >> 40));
             }
@@ -376,7 +381,7 @@ __device__ __forceinline__ void tile_classify(const u64 *buf, int cnt, u64 prevE
         int c = CLS_NONE;
         u32 g = 0, sp = 0;
         if (idx < cnt) {
-            u64 e = buf[idx];
+            u64 e = BUFX(idx);
             u32 gb = (MODE == MODE_ROUND0) ? 0u : (u32)(e >> 40);
             g = gb + (u32)(nhi[k] - ohi[k]);
             sp = gb + (u32)(idx - ohi[k]);
@@ -394,7 +399,7 @@ __device__ __forceinline__ void tile_classify(const u64 *buf, int cnt, u64 prevE
 }
 
 // shared output stage: ranks, BWT bytes of finished rotations, survivors to the S / L lists
-template <int MODE>
+template <int MODE, bool SWZ = false>
 __device__ __forceinline__ void tile_emit(const u64 *buf, int cnt, const int (&cls)[16],
                                           const u32 (&ngrp)[16], const u32 (&spos)[16],
                                           u32 *__restrict__ rank, const u8 *__restrict__ T,
@@ -439,7 +444,7 @@ __device__ __forceinline__ void tile_emit(const u64 *buf, int cnt, const int (&c
         const int c = cls[k];
         u32 i = 0;
         if (c != CLS_NONE) {
-            i = (u32)(buf[idx] & E_IMASK);
+            i = (u32)(BUFX(idx) & E_IMASK);
             if (MODE != MODE_FINAL) rank[i] = ngrp[k];
             if (MODE == MODE_FINAL || c == CLS_SINGLE) bwt[spos[k]] = T[i == 0 ? n - 1 : i - 1];
         }
@@ -587,21 +592,88 @@ __global__ __launch_bounds__(RT_THREADS) void k2_lrerank_p3(
 }
 
 // ------------------------------------------------------------------ S-path: sort in LDS
-__device__ __forceinline__ void bitonic_sort_lds(u64 *buf, int N) {
-    for (int k = 2; k <= N; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int p = threadIdx.x; p < (N >> 1); p += RT_THREADS) {
-                int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
-                int l = i | j;
-                u64 a = buf[i], c = buf[l];
-                bool asc = (i & k) == 0;
-                if ((a > c) == asc) {
-                    buf[i] = c;
-                    buf[l] = a;
+// Bitonic sort of buf[0..N) (swizzled indexing, N a power of two >= 64).  The network's
+// sub-stages are grouped by the bit they exchange on: [0,4), [4,8), [8,12).  For each group a
+// thread loads the 2^W elements that differ only in those bits, runs all the group's sub-stages
+// of the current merge phase in registers, and stores them back: 21 LDS round trips for N = 4096
+// instead of 78.
+template <int W>
+__device__ __forceinline__ void bitonic_pass(u64 *buf, int logN, int lo, int kk) {
+    const int t = threadIdx.x;
+    if (t < ((1 << logN) >> W)) {
+        const int low = t & ((1 << lo) - 1), high = t >> lo;
+        const int base = low | (high << (lo + W));
+        u64 v[1 << W];
+#pragma unroll
+        for (int m = 0; m < (1 << W); m++) v[m] = buf[SZ(base | (m << lo))];
+#pragma unroll
+        for (int s = W - 1; s >= 0; s--) {
+            if (lo + s < kk) {
+#pragma unroll
+                for (int m = 0; m < (1 << W); m++) {
+                    if (!(m & (1 << s))) {
+                        const int idx = base | (m << lo);
+                        const bool asc = ((idx >> kk) & 1) == 0;
+                        const u64 a = v[m], c = v[m | (1 << s)];
+                        const bool sw = (a > c) == asc;
+                        v[m] = sw ? c : a;
+                        v[m | (1 << s)] = sw ? a : c;
+                    }
                 }
             }
-            __syncthreads();
         }
+#pragma unroll
+        for (int m = 0; m < (1 << W); m++) buf[SZ(base | (m << lo))] = v[m];
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void bitonic_sort_lds(u64 *buf, int N) {
+    const int logN = 31 - __clz(N);
+    {
+        // merge phases 1..4 only touch bits 0..3: one round trip
+        const int t = threadIdx.x;
+        if (t < (N >> 4)) {
+            const int base = t << 4;
+            u64 v[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++) v[m] = buf[SZ(base | m)];
+#pragma unroll
+            for (int kk = 1; kk <= 4; kk++) {
+#pragma unroll
+                for (int s = kk - 1; s >= 0; s--) {
+#pragma unroll
+                    for (int m = 0; m < 16; m++) {
+                        if (!(m & (1 << s))) {
+                            const bool asc = (((base | m) >> kk) & 1) == 0;
+                            const u64 a = v[m], c = v[m | (1 << s)];
+                            const bool sw = (a > c) == asc;
+                            v[m] = sw ? c : a;
+                            v[m | (1 << s)] = sw ? a : c;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 16; m++) buf[SZ(base | m)] = v[m];
+        }
+        __syncthreads();
+    }
+    for (int kk = 5; kk <= logN; kk++) {
+        if (kk > 8) {
+            switch (logN - 8) {
+            case 1: bitonic_pass<1>(buf, logN, 8, kk); break;
+            case 2: bitonic_pass<2>(buf, logN, 8, kk); break;
+            case 3: bitonic_pass<3>(buf, logN, 8, kk); break;
+            default: bitonic_pass<4>(buf, logN, 8, kk); break;
+            }
+        }
+        switch (logN - 4) {
+        case 2: bitonic_pass<2>(buf, logN, 4, kk); break;
+        case 3: bitonic_pass<3>(buf, logN, 4, kk); break;
+        default: bitonic_pass<4>(buf, logN, 4, kk); break;
+        }
+        bitonic_pass<4>(buf, logN, 0, kk);
     }
 }
 
@@ -723,7 +795,7 @@ __global__ void k2_runs(const u8 *__restrict__ T, const u32 *__restrict__ nArr,
 }
 
 template <int MODE>
-__global__ __launch_bounds__(RT_THREADS, 4) void k2_ssort(const u64 *slA, const u64 *slB,
+__global__ __launch_bounds__(RT_THREADS, 3) void k2_ssort(const u64 *slA, const u64 *slB,
                                                        u64 *slAo, u64 *slBo,
                                                        const u32 *__restrict__ par,
                                                        const u32 *__restrict__ mS,
@@ -773,7 +845,7 @@ __global__ __launch_bounds__(RT_THREADS, 4) void k2_ssort(const u64 *slA, const 
                 else myEnd = min(myEnd, q);
             }
         }
-        buf[q] = e;
+        buf[SZ(q)] = e;
     }
     if (myStart != CROSS) atomicMin(&s_start, myStart);
     if (myEnd != CROSS) atomicMin(&s_end, myEnd);
@@ -807,10 +879,10 @@ __global__ __launch_bounds__(RT_THREADS, 4) void k2_ssort(const u64 *slA, const 
             u32 f = 0, vd = 0;
             u64 e = ~0ull;
             if (q >= start && q < end) {
-                e = buf[q];
+                e = buf[SZ(q)];
                 if (q == start) head = true;
                 else {
-                    u64 ep = buf[q - 1];
+                    u64 ep = buf[SZ(q - 1)];
                     head = (e >> 40) != (ep >> 40);
                     if (!head) {
                         const u32 k2 = (u32)(e >> KEY_SHIFT) & 0xFFFFFu, k2p = (u32)(ep >> KEY_SHIFT) & 0xFFFFFu;
@@ -831,7 +903,7 @@ __global__ __launch_bounds__(RT_THREADS, 4) void k2_ssort(const u64 *slA, const 
                             vd = d;
                         }
                         if (q - 2 >= start) {
-                            u64 epp = buf[q - 2];
+                            u64 epp = buf[SZ(q - 2)];
                             if ((epp >> 40) == (e >> 40) && i0 - (u32)(epp & E_IMASK) != d) f |= GF_NONAP;
                         }
                     }
@@ -916,7 +988,7 @@ __global__ __launch_bounds__(RT_THREADS, 4) void k2_ssort(const u64 *slA, const 
         const u64 lt = (1ull << lane) - 1ull;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            if ((nmask[k] >> lane) & 1ull) buf[nRun + __popcll(nmask[k] & lt)] = ev[k];
+            if ((nmask[k] >> lane) & 1ull) buf[SZ((int)(nRun + __popcll(nmask[k] & lt)))] = ev[k];
             if ((umask[k] >> lane) & 1ull)
                 out[uRun + __popcll(umask[k] & lt)] = ev[k] & ~(0xFFFFFull << KEY_SHIFT);
             nRun += __popcll(nmask[k]);
@@ -927,7 +999,7 @@ __global__ __launch_bounds__(RT_THREADS, 4) void k2_ssort(const u64 *slA, const 
         int N = 64;
         while (N < cnt) N <<= 1;
         __syncthreads();
-        for (int q = cnt + threadIdx.x; q < N; q += RT_THREADS) buf[q] = ~0ull;
+        for (int q = cnt + threadIdx.x; q < N; q += RT_THREADS) buf[SZ(q)] = ~0ull;
         __syncthreads();
 #ifndef EXP_NOSORT
         bitonic_sort_lds(buf, N);
@@ -937,16 +1009,16 @@ __global__ __launch_bounds__(RT_THREADS, 4) void k2_ssort(const u64 *slA, const 
         int N = 256;
         while (N < end) N <<= 1;
         for (int q = threadIdx.x; q < N; q += RT_THREADS)
-            if (q < start || q >= end) buf[q] = ~0ull;
+            if (q < start || q >= end) buf[SZ(q)] = ~0ull;
         __syncthreads();
         bitonic_sort_lds(buf, N);
     }
     int cls[16];
     u32 ngrp[16], spos[16];
     int nheads;
-    tile_classify<MODE>(buf, cnt, 0, false, NOHEAD, NOHEAD, true, sm, cls, ngrp, spos, nheads);
+    tile_classify<MODE, true>(buf, cnt, 0, false, NOHEAD, NOHEAD, true, sm, cls, ngrp, spos, nheads);
     if (MODE == MODE_FINAL && threadIdx.x == 0) atomicAdd(&leftg[b], (u32)nheads);
-    tile_emit<MODE>(buf, cnt, cls, ngrp, spos, rank + (size_t)b * S, T + (size_t)b * S,
+    tile_emit<MODE, true>(buf, cnt, cls, ngrp, spos, rank + (size_t)b * S, T + (size_t)b * S,
                     bwt + (size_t)b * S, nArr[b], out, mSn + b, (u64 *)nullptr, 0, sm);
 }
 
