@@ -794,6 +794,259 @@ __global__ void k2_runs(const u8 *__restrict__ T, const u32 *__restrict__ nArr,
     R[0] = cnt;
 }
 
+
+// ------------------------------------------------------------------ long-repeat rules on the L-list
+// Same rules as in k2_ssort (arithmetic progression with p <= h, run rule) for groups that are too
+// large for an S-window.  The L-list (keyA, k2 already gathered) is grouped and in index order
+// inside groups; a group may span tiles, so its flags are OR-ed in three steps:
+//   lap_p1  per tile: first/last head, flags of the elements before the first head and from the
+//           last head on
+//   lap_p2  per block: walk the tiles forward and backward -> for every tile the complete flags
+//           and head position of the group entering it and of the group still open at its end
+//   lap_p3  per tile: groups that qualify get k2 := slot (or its complement); the radix sort and
+//           re-rank of this round then finish them as singletons.
+__device__ __forceinline__ u32 lap_pair_flags(u64 e, u64 ep, bool has_pp, u64 epp, u32 hcur,
+                                              const u32 *s_runs) {
+    u32 f = 0;
+    const u32 k2 = (u32)(e >> KEY_SHIFT) & 0xFFFFFu, k2p = (u32)(ep >> KEY_SHIFT) & 0xFFFFFu;
+    if (k2 != k2p) f |= (k2 > k2p) ? (GF_NONUNI | GF_ASC) : (GF_NONUNI | GF_DESC);
+    const u32 i1 = (u32)(e & E_IMASK), i0 = (u32)(ep & E_IMASK);
+    const u32 d = i1 - i0;
+    if (i1 <= i0) f |= GF_NONAP;
+    else if (d > hcur) {
+        u32 ok = 0;
+        const u32 nr = s_runs[0];
+        for (u32 r = 0; r < nr; r++) {
+            const u32 *R = s_runs + 4 + 4 * r;
+            if (R[0] == d && i0 >= R[1] && i1 <= R[2]) ok = R[3];
+        }
+        f |= ok ? (GF_RUN | ok) : GF_NONAP;
+    }
+    if (has_pp && (epp >> 40) == (e >> 40) && i0 - (u32)(epp & E_IMASK) != d) f |= GF_NONAP;
+    return f;
+}
+
+__device__ __forceinline__ bool lap_qualifies(u32 gf) {
+    const u32 dir = gf & (GF_ASC | GF_DESC);
+    return (gf & (GF_NONUNI | GF_RUN)) && !(gf & GF_NONAP) && (dir == GF_ASC || dir == GF_DESC);
+}
+
+#define LAP_LOAD()                                                                              \
+    const u64 *list = keyA + (size_t)b * S;                                                     \
+    u64 ev[RT_ITEMS];                                                                           \
+    u32 fl[RT_ITEMS];                                                                           \
+    u64 hm[RT_ITEMS];                                                                           \
+    _Pragma("unroll") for (int k = 0; k < RT_ITEMS; k++) {                                      \
+        const u32 j = base + (u32)(w * 1024 + k * 64 + lane);                                   \
+        bool head = false;                                                                      \
+        u32 f = 0;                                                                              \
+        u64 e = 0;                                                                              \
+        if (j < m) {                                                                            \
+            e = list[j];                                                                        \
+            if (j == 0) head = true;                                                            \
+            else {                                                                              \
+                const u64 ep = list[j - 1];                                                     \
+                head = (e >> 40) != (ep >> 40);                                                 \
+                if (!head) f = lap_pair_flags(e, ep, j >= 2, j >= 2 ? list[j - 2] : 0ull, hcur, s_runs); \
+            }                                                                                   \
+        }                                                                                       \
+        ev[k] = e;                                                                              \
+        fl[k] = f;                                                                              \
+        hm[k] = __ballot(head);                                                                 \
+    }
+
+__global__ __launch_bounds__(RT_THREADS) void k2_lap_p1(const u64 *__restrict__ keyA,
+                                                        const u32 *__restrict__ mL,
+                                                        const u32 *__restrict__ state,
+                                                        const u32 *__restrict__ huse,
+                                                        const u32 *__restrict__ runs,
+                                                        u32 *__restrict__ pvote,
+                                                        u32 *__restrict__ lagg, u32 S, u32 TPB,
+                                                        u32 gtiles, u32 gnb) {
+    XCD_MAP(gtiles, gnb)
+    const u32 b = bz_b;
+    if (state[b] != ST_ACTIVE) return;
+    const u32 m = mL[b];
+    const u32 base = bz_t * RTILE;
+    if (base >= m) return;
+    __shared__ u32 s_runs[RUNS_STRIDE];
+    __shared__ u32 sm[8];
+    __shared__ u32 s_or[2];
+    if (threadIdx.x < RUNS_STRIDE) s_runs[threadIdx.x] = runs ? runs[(size_t)b * RUNS_STRIDE + threadIdx.x] : 0u;
+    if (threadIdx.x < 2) s_or[threadIdx.x] = 0;
+    __syncthreads();
+    const int w = wave_id(), lane = lane_id();
+    const u32 hcur = huse[b];
+    LAP_LOAD()
+    if (pvote && w == 0) {
+        // votes from the first row of the tile, one atomic per stretch of equal distances
+        const u32 j = base + (u32)lane;
+        u32 vd = 0;
+        if (j >= 1 && j < m && !((hm[0] >> lane) & 1ull)) {
+            const u32 i1 = (u32)(ev[0] & E_IMASK), i0 = (u32)(list[j - 1] & E_IMASK);
+            if (i1 > i0 && i1 - i0 > hcur) vd = i1 - i0;
+        }
+        const u32 vprev = __shfl_up(vd, 1, 64);
+        const bool vote = vd != 0;
+        const bool rh = vote && (lane == 0 || vprev != vd);
+        const u64 hm_ = __ballot(rh), vm_ = __ballot(vote);
+        if (rh) {
+            const u64 above = (lane == 63) ? 0ull : ((hm_ | ~vm_) & (~0ull << (lane + 1)));
+            const u32 cnt = (above ? (u32)__ffsll((unsigned long long)above) - 1u : 64u) - (u32)lane;
+            u32 *pv = pvote + ((size_t)b * VT + VSLOT(vd)) * 2;
+            atomicAdd(pv, cnt);
+            pv[1] = vd;
+        }
+    }
+    // first / last head slot of the tile (+1, 0 = none)
+    u32 firstH = 0xFFFFFFFFu, lastH = 0;
+#pragma unroll
+    for (int k = 0; k < RT_ITEMS; k++) {
+        if (hm[k]) {
+            const u32 rb = (u32)(w * 1024 + k * 64);
+            firstH = min(firstH, rb + (u32)__ffsll((unsigned long long)hm[k]) - 1u);
+            lastH = max(lastH, rb + 64u - (u32)__clzll((unsigned long long)hm[k]));
+        }
+    }
+    lastH = block_reduce_max<RT_THREADS>(lastH, sm);                // last head slot + 1
+    firstH = ~block_reduce_max<RT_THREADS>(~firstH, sm);            // first head slot or ~0
+    u32 pre = 0, suf = 0;
+#pragma unroll
+    for (int k = 0; k < RT_ITEMS; k++) {
+        const u32 idx = (u32)(w * 1024 + k * 64 + lane);
+        if (idx < firstH) pre |= fl[k];
+        if (lastH && idx >= lastH - 1u) suf |= fl[k];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        pre |= __shfl_xor(pre, d, 64);
+        suf |= __shfl_xor(suf, d, 64);
+    }
+    if (lane == 0) {
+        if (pre) atomicOr(&s_or[0], pre);
+        if (suf) atomicOr(&s_or[1], suf);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 *o = lagg + ((size_t)b * TPB + bz_t) * 4;
+        o[0] = (firstH == 0xFFFFFFFFu) ? 0u : firstH + 1u;
+        o[1] = lastH;
+        o[2] = s_or[0];
+        o[3] = s_or[1];
+    }
+}
+
+__global__ __launch_bounds__(256) void k2_lap_p2(const u32 *__restrict__ mL,
+                                                 const u32 *__restrict__ state,
+                                                 const u32 *__restrict__ lagg,
+                                                 u32 *__restrict__ lres, u32 TPB) {
+    const u32 b = blockIdx.x;
+    if (state[b] != ST_ACTIVE) return;
+    const u32 m = mL[b];
+    const u32 tiles = (m + RTILE - 1) / RTILE;
+    if (!tiles) return;
+    extern __shared__ u32 lds[]; // [tiles][4] in, then [tiles][4] out
+    u32 *in = lds, *out = lds + (size_t)TPB * 4;
+    for (u32 q = threadIdx.x; q < tiles * 4; q += 256) in[q] = lagg[(size_t)b * TPB * 4 + q];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // forward: flags gathered so far by the group that enters tile t, and its head position
+        u32 carryF = 0, carryHead = 0;
+        for (u32 t = 0; t < tiles; t++) {
+            out[t * 4 + 0] = carryHead;
+            out[t * 4 + 1] = carryF; // completed below
+            if (in[t * 4 + 1]) {
+                carryF = in[t * 4 + 3];
+                carryHead = t * RTILE + in[t * 4 + 1] - 1u;
+            } else {
+                carryF |= in[t * 4 + 2];
+            }
+        }
+        // backward: what the entering group still collects from tile t onward
+        u32 after = 0; // of tile t + 1
+        for (u32 t = tiles; t-- > 0;) {
+            const bool hasHead = in[t * 4 + 1] != 0;
+            out[t * 4 + 2] = in[t * 4 + 3] | after;                  // group open at the end of t
+            const u32 mine = hasHead ? in[t * 4 + 2] : (in[t * 4 + 2] | after);
+            out[t * 4 + 1] |= mine;                                  // group entering t
+            after = mine;
+        }
+    }
+    __syncthreads();
+    for (u32 q = threadIdx.x; q < tiles * 4; q += 256) lres[(size_t)b * TPB * 4 + q] = out[q];
+}
+
+__global__ __launch_bounds__(RT_THREADS) void k2_lap_p3(u64 *__restrict__ keyA,
+                                                        const u32 *__restrict__ mL,
+                                                        const u32 *__restrict__ state,
+                                                        const u32 *__restrict__ huse,
+                                                        const u32 *__restrict__ runs,
+                                                        const u32 *__restrict__ lagg,
+                                                        const u32 *__restrict__ lres, u32 S, u32 TPB,
+                                                        u32 gtiles, u32 gnb) {
+    XCD_MAP(gtiles, gnb)
+    const u32 b = bz_b;
+    if (state[b] != ST_ACTIVE) return;
+    const u32 m = mL[b];
+    const u32 base = bz_t * RTILE;
+    if (base >= m) return;
+    __shared__ u32 s_runs[RUNS_STRIDE];
+    __shared__ int sm[8];
+    __shared__ u32 gfl[RTILE]; // flags of the groups that start in this tile, at their head slot
+    if (threadIdx.x < RUNS_STRIDE) s_runs[threadIdx.x] = runs ? runs[(size_t)b * RUNS_STRIDE + threadIdx.x] : 0u;
+    for (int q = threadIdx.x; q < RTILE; q += RT_THREADS) gfl[q] = 0;
+    __syncthreads();
+    const int w = wave_id(), lane = lane_id();
+    const u32 hcur = huse[b];
+    LAP_LOAD()
+    const u32 *ag = lagg + ((size_t)b * TPB + bz_t) * 4;
+    const u32 *rs = lres + ((size_t)b * TPB + bz_t) * 4;
+    const u32 lastH = ag[1];                      // last head slot + 1 (0 = none)
+    const u32 inHead = rs[0], inF = rs[1], openF = rs[2];
+    // head slot of every element (NOHEAD = the group entered from an earlier tile)
+    int lastHead = NOHEAD;
+#pragma unroll
+    for (int k = 0; k < RT_ITEMS; k++)
+        if (hm[k]) lastHead = w * 1024 + k * 64 + 63 - __clzll((unsigned long long)hm[k]);
+    if (lane == 0) sm[w] = lastHead;
+    __syncthreads();
+    int cO = NOHEAD;
+    for (int q = 0; q < w; q++)
+        if (sm[q] != NOHEAD) cO = sm[q];
+    int ohi[RT_ITEMS];
+    const u64 le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+#pragma unroll
+    for (int k = 0; k < RT_ITEMS; k++) {
+        const int rb = w * 1024 + k * 64;
+        const u64 mo = hm[k] & le;
+        ohi[k] = mo ? rb + 63 - __clzll((unsigned long long)mo) : cO;
+        if (hm[k]) cO = rb + 63 - __clzll((unsigned long long)hm[k]);
+        if (fl[k] && ohi[k] != NOHEAD) atomicOr(&gfl[ohi[k]], fl[k]);
+    }
+    __syncthreads();
+    // (neighbour tiles read only grp and i of this tile's elements, which stay as they are)
+    u64 *lwr = keyA + (size_t)b * S;
+#pragma unroll
+    for (int k = 0; k < RT_ITEMS; k++) {
+        const u32 idx = (u32)(w * 1024 + k * 64 + lane);
+        const u32 j = base + idx;
+        if (j >= m) continue;
+        u32 gf, headpos;
+        if (ohi[k] == NOHEAD) {
+            gf = inF;
+            headpos = inHead;
+        } else {
+            gf = (lastH && (u32)ohi[k] == lastH - 1u) ? openF : gfl[ohi[k]];
+            headpos = base + (u32)ohi[k];
+        }
+        if (lap_qualifies(gf)) {
+            const u32 slot = j - headpos;
+            const u32 code = (gf & GF_ASC) ? slot : (0xFFFFFu - slot);
+            lwr[j] = (ev[k] & ~(0xFFFFFull << KEY_SHIFT)) | ((u64)code << KEY_SHIFT);
+        }
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(RT_THREADS, 3) void k2_ssort(const u64 *slA, const u64 *slB,
                                                        u64 *slAo, u64 *slBo,
@@ -1153,7 +1406,7 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
     else radix_sort5(c, nb, maxn, B.n, B.keyB, B.keyA, r0p);
     lrerank<MODE_ROUND0>(c, nb, maxn, B.n, ST_ACTIVE, B.keyB, B.keyA);
     bool first = true;
-    int rnd = 0; // S-rounds launched so far
+    int rnd = 0; // doubling rounds launched so far
     HIPCHK(hipMemsetAsync(B.pvote, 0, (size_t)nb * VT * 2 * sizeof(u32), c->stream));
     u32 finS = 0, finL = 0;
     bool anyfin = false;
@@ -1204,21 +1457,38 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
                 B.mSn, B.leftg, B.huse, rnd == 0 ? B.pvote : (u32 *)nullptr,
                 rnd == 0 ? (const u32 *)nullptr : B.runs, B.S, (maxS + SC - 1) / SC, nbarg(nb, 2));
             KCHECK();
-            if (rnd == 0) {
-                k2_pick<<<nb, 256, 0, c->stream>>>(B.pvote, B.n, B.cand, B.runs, nb);
-                KCHECK();
-                k2_viol<<<dim3(tiles, NCAND, nb), 256, 0, c->stream>>>(B.T, B.n, B.cand, B.vagg, B.S, B.TPB);
-                KCHECK();
-                k2_runs<<<cb, 256, 0, c->stream>>>(B.T, B.n, B.cand, B.vagg, B.runs, B.S, B.TPB, nb);
-                KCHECK();
-            }
             KCHECK();
         }
         if (maxL) {
+            {
+                // long-repeat rules on the L-list (after k2_keys, before the sort)
+                ProfScope ps(c, P_BWT_KEYS);
+                const u32 lt = (maxL + RTILE - 1) / RTILE;
+                const u32 *runs = rnd == 0 ? (const u32 *)nullptr : B.runs;
+                k2_lap_p1<<<xcd_grid(lt, nb), RT_THREADS, 0, c->stream>>>(B.keyA, B.mL, B.state, B.huse, runs,
+                                                                         rnd == 0 ? B.pvote : (u32 *)nullptr, B.tileagg, B.S, B.TPB, lt, nbarg(nb, 4));
+                KCHECK();
+                k2_lap_p2<<<nb, 256, (size_t)B.TPB * 8 * sizeof(u32), c->stream>>>(B.mL, B.state, B.tileagg,
+                                                                                   B.r2agg, B.TPB);
+                KCHECK();
+                k2_lap_p3<<<xcd_grid(lt, nb), RT_THREADS, 0, c->stream>>>(B.keyA, B.mL, B.state, B.huse, runs,
+                                                                         B.tileagg, B.r2agg, B.S, B.TPB, lt,
+                                                                         nbarg(nb, 4));
+                KCHECK();
+            }
             radix_sort5(c, nb, maxL, B.mL, B.keyA, B.keyB);
             lrerank<MODE_NORMAL>(c, nb, maxL, B.mL, ST_ACTIVE, B.keyB, B.keyA);
         }
-        if (maxS) rnd++;
+        if (rnd == 0) {
+            // the first round voted for repeat distances (S- and L-list): list their regions
+            k2_pick<<<nb, 256, 0, c->stream>>>(B.pvote, B.n, B.cand, B.runs, nb);
+            KCHECK();
+            k2_viol<<<dim3(tiles, NCAND, nb), 256, 0, c->stream>>>(B.T, B.n, B.cand, B.vagg, B.S, B.TPB);
+            KCHECK();
+            k2_runs<<<cb, 256, 0, c->stream>>>(B.T, B.n, B.cand, B.vagg, B.runs, B.S, B.TPB, nb);
+            KCHECK();
+        }
+        rnd++;
     }
     if (anyfin) {
         // periodic blocks: flush the k-fold ties in list order

@@ -275,3 +275,50 @@ def test_sharded_engine_on_gpu(ctx, orc):
     for r in (2, 1, 0):  # rank 0 last, once every shard exists
         out = parallel.compress_sharded(d, 3, ctx, rank=r, world=3, gather=make_gather(r))
     assert out == want
+
+
+def _repeat_family(seed):
+    """Inputs built to exercise the long-repeat rules of the sorter (k2_bwt.hip: arithmetic
+    progression rule, run rule): periodic regions of many periods and lengths, with mutations,
+    duplicated chunks at a fixed distance, regions touching the block start / end."""
+    rng = np.random.default_rng(seed)
+    out = {}
+
+    def rnd(n, a=256):
+        return rng.integers(0, a, n, dtype=np.uint8)
+
+    for t in range(6):
+        p = int(rng.choice([1, 2, 3, 7, 64, 255, 256, 257, 1000, 4097, 30000, 65536]))
+        reps = int(rng.integers(2, 40)) if p > 1000 else int(rng.integers(20, 3000))
+        alpha = int(rng.choice([2, 4, 256]))
+        unit = rnd(p, alpha)
+        body = np.tile(unit, reps)[: int(rng.integers(p + 1, max(p + 2, min(p * reps, 400000))))]
+        pre = rnd(int(rng.integers(0, 3)) * int(rng.integers(0, 20000)))
+        post = rnd(int(rng.integers(0, 3)) * int(rng.integers(0, 20000)))
+        out[f"per{t}_p{p}"] = np.concatenate([pre, body, post])
+        # one mutation in the middle of the periodic region
+        m = body.copy()
+        if m.size > 10:
+            m[m.size // 2] ^= 1
+        out[f"mut{t}_p{p}"] = np.concatenate([post, m, pre])
+    for t in range(4):
+        # a chunk duplicated once or twice at a fixed distance (groups of 2 and 3)
+        chunk = rnd(int(rng.integers(5000, 120000)), int(rng.choice([4, 256])))
+        gap = rnd(int(rng.integers(0, 30000)))
+        out[f"dup{t}"] = np.concatenate([rnd(int(rng.integers(0, 5000))), chunk, gap, chunk, gap[: gap.size // 2], chunk[: chunk.size // 2]])
+    # two different periodic regions in one block, same and different periods
+    u1, u2 = rnd(5000), rnd(5000)
+    out["two_regions_same_p"] = np.concatenate([np.tile(u1, 20), rnd(777), np.tile(u2, 20), rnd(3)])
+    out["two_regions_same_unit"] = np.concatenate([np.tile(u1, 15), rnd(1234), np.tile(u1, 17)])
+    out["nested_period"] = np.tile(np.concatenate([np.tile(rnd(50), 40), rnd(13)]), 60)
+    out["wrap_region"] = np.concatenate([np.tile(u2, 10)[2500:], rnd(40000), np.tile(u2, 10)[:2500]])
+    return out
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_long_repeat_rules(ctx, orc, seed):
+    for name, d in _repeat_family(seed).items():
+        for level in (1, 9):
+            want, _ = orc.compress(d, level)
+            got = ctx.compress(d, level)
+            assert got == want, (name, level, d.size)
