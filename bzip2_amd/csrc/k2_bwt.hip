@@ -717,7 +717,7 @@ __global__ __launch_bounds__(256) void k2_pick(const u32 *__restrict__ pvote,
         best = block_reduce_max<256>(best, sm);
         if (pass == 0) first = best;
         if (threadIdx.x == 0) {
-            u32 pp = best ? pv[2 * (best & (VT - 1)) + 1] : 0;
+            u32 pp = best ? (pv[2 * (best & (VT - 1)) + 1] & 0xFFFFFu) : 0;
             if (pp == 0 || pp >= n) pp = 0;
             cand[b * NCAND + pass] = pp;
         }
@@ -883,8 +883,10 @@ __global__ __launch_bounds__(RT_THREADS) void k2_lap_p1(const u64 *__restrict__ 
         const u32 j = base + (u32)lane;
         u32 vd = 0;
         if (j >= 1 && j < m && !((hm[0] >> lane) & 1ull)) {
-            const u32 i1 = (u32)(ev[0] & E_IMASK), i0 = (u32)(list[j - 1] & E_IMASK);
-            if (i1 > i0 && i1 - i0 > hcur) vd = i1 - i0;
+            const u64 ep = list[j - 1];
+            const u32 i1 = (u32)(ev[0] & E_IMASK), i0 = (u32)(ep & E_IMASK);
+            const bool same_k2 = ((ev[0] ^ ep) >> KEY_SHIFT & 0xFFFFFull) == 0;
+            if (same_k2 && i1 > i0 && i1 - i0 > hcur) vd = i1 - i0;
         }
         const u32 vprev = __shfl_up(vd, 1, 64);
         const bool vote = vd != 0;
@@ -895,7 +897,7 @@ __global__ __launch_bounds__(RT_THREADS) void k2_lap_p1(const u64 *__restrict__ 
             const u32 cnt = (above ? (u32)__ffsll((unsigned long long)above) - 1u : 64u) - (u32)lane;
             u32 *pv = pvote + ((size_t)b * VT + VSLOT(vd)) * 2;
             atomicAdd(pv, cnt);
-            pv[1] = vd;
+            atomicMax(pv + 1, (cnt << 20) | vd);
         }
     }
     // first / last head slot of the tile (+1, 0 = none)
@@ -1153,7 +1155,7 @@ __global__ __launch_bounds__(RT_THREADS, 3) void k2_ssort(const u64 *slA, const 
                                 if (R[0] == d && i0 >= R[1] && i1 <= R[2]) ok = R[3];
                             }
                             f |= ok ? (GF_RUN | ok) : GF_NONAP;
-                            vd = d;
+                            if (!diff) vd = d; // only pairs that do not split this round vote
                         }
                         if (q - 2 >= start) {
                             u64 epp = buf[SZ(q - 2)];
@@ -1172,9 +1174,11 @@ __global__ __launch_bounds__(RT_THREADS, 3) void k2_ssort(const u64 *slA, const 
                 if (rh) {
                     const u64 above = (lane == 63) ? 0ull : ((hm_ | ~vm_) & (~0ull << (lane + 1)));
                     const u32 cnt = (above ? (u32)__ffsll((unsigned long long)above) - 1u : 64u) - (u32)lane;
+                    // count: sum; distance: the one with the longest stretch, then the largest
+                    // (both independent of the order the votes arrive in)
                     u32 *pv = pvote + ((size_t)b * VT + VSLOT(vd)) * 2;
                     atomicAdd(pv, cnt);
-                    pv[1] = vd;
+                    atomicMax(pv + 1, (cnt << 20) | vd);
                 }
             }
             ev[k] = e;
