@@ -158,7 +158,7 @@ __global__ __launch_bounds__(RT_THREADS) void k2_radix_hist(const u64 *__restric
 #pragma unroll
     for (int k = 0; k < RT_ITEMS; k++) {
         u32 i = base + k * RT_THREADS + threadIdx.x;
-        if (i < n) atomicAdd(&hist[(u32)(kp[i] >> shift) & 255u], 1u);
+        if (i < n) atomicAdd(&hist[(u32)(__builtin_nontemporal_load(&kp[i]) >> shift) & 255u], 1u);
     }
     __syncthreads();
     tilehist[((size_t)b * TPB + bz_t) * 256 + threadIdx.x] = hist[threadIdx.x];
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(RT_THREADS) void k2_radix_scatter(
     for (int k = 0; k < RT_ITEMS; k++) {
         u32 i = base + w * (RTILE / 4) + k * 64 + lane;
         bool valid = i < n;
-        u64 kk = valid ? kp[i] : 0;
+        u64 kk = valid ? __builtin_nontemporal_load(&kp[i]) : 0;
         keys[k] = kk;
         u32 d = (u32)(kk >> shift) & 255u;
         u64 m = match8(d, valid);
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(RT_THREADS) void k2_radix_scatter(
         u32 i = base + w * (RTILE / 4) + k * 64 + lane;
         if (i < n) {
             u32 d = (u32)(keys[k] >> shift) & 255u;
-            ko[gofs[d] + whist[w][d] + lr[k]] = keys[k];
+            ko[gofs[d] + whist[w][d] + lr[k]] = keys[k]; // (not nontemporal: L2 merges these into full lines)
         }
     }
 }
@@ -451,8 +451,9 @@ __device__ __forceinline__ void tile_emit(const u64 *buf, int cnt, const int (&c
         if (MODE != MODE_FINAL) {
             u64 ms = __ballot(c == CLS_SMALL), ml = __ballot(c == CLS_LKEEP);
             const u64 lt = (1ull << lane) - 1ull;
-            if (c == CLS_SMALL) sOut[sRun + __popcll(ms & lt)] = ((u64)ngrp[k] << 40) | i;
-            if (c == CLS_LKEEP) lOut[lRun + __popcll(ml & lt)] = ((u64)ngrp[k] << 40) | i;
+            // list traffic is streaming: keep it from evicting the rank / BWT lines being scattered into
+            if (c == CLS_SMALL) __builtin_nontemporal_store(((u64)ngrp[k] << 40) | i, &sOut[sRun + __popcll(ms & lt)]);
+            if (c == CLS_LKEEP) __builtin_nontemporal_store(((u64)ngrp[k] << 40) | i, &lOut[lRun + __popcll(ml & lt)]);
             sRun += __popcll(ms);
             lRun += __popcll(ml);
         }
@@ -476,7 +477,7 @@ __global__ __launch_bounds__(RT_THREADS) void k2_lrerank_p1(const u64 *__restric
     __shared__ int sm[16];
     const u64 *kp = key + (size_t)b * S;
     const int cnt = (int)min((u32)RTILE, m - base);
-    for (int q = threadIdx.x; q < RTILE; q += RT_THREADS) buf[q] = (q < cnt) ? kp[base + q] : ~0ull;
+    for (int q = threadIdx.x; q < RTILE; q += RT_THREADS) buf[q] = (q < cnt) ? __builtin_nontemporal_load(&kp[base + q]) : ~0ull;
     const bool has_prev = base > 0;
     const u64 prevE = has_prev ? kp[base - 1] : 0;
     bool end_head = true;
@@ -571,7 +572,7 @@ __global__ __launch_bounds__(RT_THREADS) void k2_lrerank_p3(
     __shared__ int sm[16];
     const u64 *kp = key + (size_t)b * S;
     const int cnt = (int)min((u32)RTILE, m - base);
-    for (int q = threadIdx.x; q < RTILE; q += RT_THREADS) buf[q] = (q < cnt) ? kp[base + q] : ~0ull;
+    for (int q = threadIdx.x; q < RTILE; q += RT_THREADS) buf[q] = (q < cnt) ? __builtin_nontemporal_load(&kp[base + q]) : ~0ull;
     const bool has_prev = base > 0;
     const u64 prevE = has_prev ? kp[base - 1] : 0;
     bool end_head = true;
@@ -1091,7 +1092,7 @@ __global__ __launch_bounds__(RT_THREADS, 3) void k2_ssort(const u64 *slA, const 
     for (int q = threadIdx.x; q < RTILE; q += RT_THREADS) {
         u64 e = ~0ull;
         if (q < loaded) {
-            e = in[t0 + q];
+            e = __builtin_nontemporal_load(&in[t0 + q]);
             bool head;
             if (q == 0) head = (t0 == 0) || ((e >> 40) != (in[t0 - 1] >> 40));
             else head = (e >> 40) != (in[t0 + q - 1] >> 40);
@@ -1247,7 +1248,7 @@ __global__ __launch_bounds__(RT_THREADS, 3) void k2_ssort(const u64 *slA, const 
         for (int k = 0; k < 16; k++) {
             if ((nmask[k] >> lane) & 1ull) buf[SZ((int)(nRun + __popcll(nmask[k] & lt)))] = ev[k];
             if ((umask[k] >> lane) & 1ull)
-                out[uRun + __popcll(umask[k] & lt)] = ev[k] & ~(0xFFFFFull << KEY_SHIFT);
+                __builtin_nontemporal_store(ev[k] & ~(0xFFFFFull << KEY_SHIFT), &out[uRun + __popcll(umask[k] & lt)]);
             nRun += __popcll(nmask[k]);
             uRun += __popcll(umask[k]);
         }
