@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "csrc", "libbz2hip.so")
+SO_PATH = os.environ.get("BZ2HIP_LIB") or os.path.join(_HERE, "csrc", "libbz2hip.so")  # override: experiments only
 
 OK, E_PARAM, E_NOMEM, E_HIP, E_CAP, E_STATE = 0, -1, -2, -3, -4, -5
 MAX_ALPHA, MAX_TABLES = 258, 6

@@ -155,10 +155,19 @@ __global__ __launch_bounds__(RT_THREADS) void k2_radix_hist(const u64 *__restric
     hist[threadIdx.x] = 0;
     __syncthreads();
     const u64 *kp = key + (size_t)b * S;
+    typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+    const u64x2 *kp2 = (const u64x2 *)(kp + base); // base is a multiple of 4096: 16-byte aligned
 #pragma unroll
-    for (int k = 0; k < RT_ITEMS; k++) {
-        u32 i = base + k * RT_THREADS + threadIdx.x;
-        if (i < n) atomicAdd(&hist[(u32)(__builtin_nontemporal_load(&kp[i]) >> shift) & 255u], 1u);
+    for (int k = 0; k < RT_ITEMS / 2; k++) {
+        const u32 q = k * RT_THREADS + threadIdx.x; // pair index inside the tile
+        const u32 i = base + 2 * q;
+        if (i + 1 < n) {
+            const u64x2 v = __builtin_nontemporal_load(&kp2[q]);
+            atomicAdd(&hist[(u32)(v.x >> shift) & 255u], 1u);
+            atomicAdd(&hist[(u32)(v.y >> shift) & 255u], 1u);
+        } else if (i < n) {
+            atomicAdd(&hist[(u32)(kp[i] >> shift) & 255u], 1u);
+        }
     }
     __syncthreads();
     tilehist[((size_t)b * TPB + bz_t) * 256 + threadIdx.x] = hist[threadIdx.x];
@@ -1259,9 +1268,7 @@ __global__ __launch_bounds__(RT_THREADS, 3) void k2_ssort(const u64 *slA, const 
         __syncthreads();
         for (int q = cnt + threadIdx.x; q < N; q += RT_THREADS) buf[SZ(q)] = ~0ull;
         __syncthreads();
-#ifndef EXP_NOSORT
         bitonic_sort_lds(buf, N);
-#endif
     } else {
         // FINAL: order inside groups is irrelevant; keep the span in place at buf[0..cnt)
         int N = 256;
