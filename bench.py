@@ -136,10 +136,20 @@ def main():
             avg_ms = sc["ms"] / launches
             alg = sc["alg_bytes"] / launches
             achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            # HBM bytes per launch from the committed PMC passes of this same command
+            # (profiles/r1_pmc_traffic.json, made by tools/profile_round.sh)
+            traffic = None
+            try:
+                with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
+                    pmc = json.load(f)
+                pmc_name = {"k2_ssort": "void k2_ssort<0>", "k3_mtf_chunks<true>": "void k3_mtf_chunks<true>"}
+                traffic = pmc[pmc_name.get(KERNEL[dom], KERNEL[dom])]["hbm_bytes_per_call"]
+            except (OSError, ValueError, KeyError):
+                traffic = None
             res["roofline"] = {"bound": "hbm", "kernel": KERNEL[dom],
                                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                               "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+                               "traffic": traffic, "avg_launch_ms": round(avg_ms, 4),
                                "launches": launches, "alg_bytes_per_launch": round(alg)}
             res["kernel_rooflines"] = {
                 KERNEL[k]: {"ms_per_step": round(prof[k]["ms"] / args.steps, 3),
