@@ -95,56 +95,55 @@ __global__ void k2_ctl(const u32 *__restrict__ nArr, u32 *mS, u32 *mL, u32 *mSn,
     }
 }
 
-// ------------------------------------------------------------------ round 0 keys
-__global__ __launch_bounds__(RT_THREADS) void k2_init_keys(const u8 *__restrict__ T,
-                                                           const u32 *__restrict__ nArr,
-                                                           const u32 *__restrict__ present,
-                                                           u64 *__restrict__ key, u32 S, u32 gtiles, u32 gnb, u32 r0bits) {
-    XCD_MAP(gtiles, gnb)
-    const u32 b = bz_b;
-    const u32 n = nArr[b];
-    const u32 base = bz_t * RTILE;
-    __shared__ u8 smap[256];
-    __shared__ u32 s_bps;
-    if (threadIdx.x < 256) {
+
+// Round-0 keys straight from the block bytes (first radix pass only): dense symbol map from the
+// present bitmap, the tile's bytes (+ the d0 - 1 that follow, cyclically) staged in LDS.
+struct R0Tile {
+    u8 smap[256];
+    u8 t[RTILE + 64];
+    u32 bps;
+};
+__device__ __forceinline__ void r0_tile_load(R0Tile &L, const u8 *__restrict__ T,
+                                             const u32 *__restrict__ present, u32 b, u32 S, u32 n,
+                                             u32 base) {
+    {
         u32 v = threadIdx.x;
         const u32 *pw = present + b * 8;
         u32 cnt = 0;
         for (u32 wi = 0; wi < (v >> 5); wi++) cnt += __popc(pw[wi]);
         cnt += __popc(pw[v >> 5] & ((1u << (v & 31)) - 1u));
-        smap[v] = (u8)cnt;
+        L.smap[v] = (u8)cnt;
         if (v == 255) {
             u32 uniq = cnt + ((pw[7] >> 31) & 1u);
             u32 bps = 1;
             while ((1u << bps) < uniq) bps++;
-            s_bps = bps;
+            L.bps = bps;
         }
+    }
+    const u8 *t = T + (size_t)b * S;
+    for (u32 q = threadIdx.x; q < RTILE + 64; q += RT_THREADS) {
+        u32 p = base + q;
+        if (p >= n) p = (p - n) % n; // cyclic continuation (n can be smaller than the overhang)
+        L.t[q] = t[p];
     }
     __syncthreads();
-    if (base >= n) return;
-    const u32 bps = s_bps;
-    const u32 d0 = r0bits / bps;
-    const u8 *t = T + (size_t)b * S;
-    for (int k = 0; k < RT_ITEMS; k++) {
-        u32 i = base + k * RT_THREADS + threadIdx.x;
-        if (i >= n) break;
-        u64 kk = 0;
-        u32 p = i;
-        for (u32 q = 0; q < d0; q++) {
-            kk = (kk << bps) | smap[t[p]];
-            p++;
-            if (p >= n) p = 0;
-        }
-        key[(size_t)b * S + i] = (kk << KEY_SHIFT) | (u64)i;
-    }
+}
+__device__ __forceinline__ u64 r0_key(const R0Tile &L, u32 local, u32 i, u32 d0) {
+    u64 kk = 0;
+    const u32 bps = L.bps;
+    for (u32 q = 0; q < d0; q++) kk = (kk << bps) | L.smap[L.t[local + q]];
+    return (kk << KEY_SHIFT) | (u64)i;
 }
 
 // ------------------------------------------------------------------ LSD radix pass (u64 words)
+template <bool FROM_T>
 __global__ __launch_bounds__(RT_THREADS) void k2_radix_hist(const u64 *__restrict__ key,
                                                             const u32 *__restrict__ cntArr,
                                                             const u32 *__restrict__ state,
                                                             u32 *__restrict__ tilehist, u32 S,
-                                                            u32 TPB, int shift, u32 gtiles, u32 gnb) {
+                                                            u32 TPB, int shift, u32 gtiles, u32 gnb,
+                                                            const u8 *__restrict__ T,
+                                                            const u32 *__restrict__ present, u32 r0bits) {
     XCD_MAP(gtiles, gnb)
     const u32 b = bz_b;
     if (state[b] != ST_ACTIVE) return;
@@ -153,6 +152,20 @@ __global__ __launch_bounds__(RT_THREADS) void k2_radix_hist(const u64 *__restric
     if (base >= n) return;
     __shared__ u32 hist[256];
     hist[threadIdx.x] = 0;
+    if (FROM_T) {
+        __shared__ R0Tile L;
+        r0_tile_load(L, T, present, b, S, n, base);
+        const u32 d0 = r0bits / L.bps;
+#pragma unroll 4
+        for (int k = 0; k < RT_ITEMS; k++) {
+            const u32 local = k * RT_THREADS + threadIdx.x;
+            if (base + local < n)
+                atomicAdd(&hist[(u32)(r0_key(L, local, base + local, d0) >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        tilehist[((size_t)b * TPB + bz_t) * 256 + threadIdx.x] = hist[threadIdx.x];
+        return;
+    }
     __syncthreads();
     const u64 *kp = key + (size_t)b * S;
     typedef u64 u64x2 __attribute__((ext_vector_type(2)));
@@ -205,10 +218,12 @@ __device__ __forceinline__ u64 match8(u32 d, bool valid) {
     return m;
 }
 
+template <bool FROM_T>
 __global__ __launch_bounds__(RT_THREADS) void k2_radix_scatter(
     const u64 *__restrict__ keyIn, u64 *__restrict__ keyOut, const u32 *__restrict__ cntArr,
     const u32 *__restrict__ state, const u32 *__restrict__ tilehist,
-    const u32 *__restrict__ digitbase, u32 S, u32 TPB, int shift, u32 gtiles, u32 gnb) {
+    const u32 *__restrict__ digitbase, u32 S, u32 TPB, int shift, u32 gtiles, u32 gnb,
+    const u8 *__restrict__ T, const u32 *__restrict__ present, u32 r0bits) {
     XCD_MAP(gtiles, gnb)
     const u32 b = bz_b;
     if (state[b] != ST_ACTIVE) return;
@@ -219,6 +234,12 @@ __global__ __launch_bounds__(RT_THREADS) void k2_radix_scatter(
     __shared__ u32 gofs[256];
     const int w = wave_id(), lane = lane_id();
     for (int q = threadIdx.x; q < 4 * 256; q += RT_THREADS) (&whist[0][0])[q] = 0;
+    __shared__ R0Tile L;
+    u32 d0 = 0;
+    if (FROM_T) {
+        r0_tile_load(L, T, present, b, S, n, base);
+        d0 = r0bits / L.bps;
+    }
     __syncthreads();
     const u64 *kp = keyIn + (size_t)b * S;
     u64 keys[RT_ITEMS];
@@ -228,7 +249,8 @@ __global__ __launch_bounds__(RT_THREADS) void k2_radix_scatter(
     for (int k = 0; k < RT_ITEMS; k++) {
         u32 i = base + w * (RTILE / 4) + k * 64 + lane;
         bool valid = i < n;
-        u64 kk = valid ? __builtin_nontemporal_load(&kp[i]) : 0;
+        u64 kk = 0;
+        if (valid) kk = FROM_T ? r0_key(L, i - base, i, d0) : __builtin_nontemporal_load(&kp[i]);
         keys[k] = kk;
         u32 d = (u32)(kk >> shift) & 255u;
         u64 m = match8(d, valid);
@@ -1345,18 +1367,23 @@ static u32 g_plain_mask = 2;
 static u32 g_r0bits = 40; // key bits of the first sort (multiple of 8)
 static inline u32 nbarg(u32 nb, u32 bit) { return (g_plain_mask & bit) ? (nb | 0x80000000u) : nb; }
 
+// `from_T`: the first pass builds the round-0 keys from the block bytes instead of reading `a`
 static void radix_sort5(bz2hip_ctx *c, int nb, u32 maxcnt, const u32 *cntArr, u64 *a, u64 *bbuf,
-                        int passes = 5) {
+                        int passes = 5, bool from_T = false) {
     Batch &B = c->batch;
     const u32 tiles = (maxcnt + RTILE - 1) / RTILE;
-    dim3 grid(tiles, nb);
     u64 *kin = a, *kout = bbuf;
     for (int p = 0; p < passes; p++) {
         int shift = KEY_SHIFT + 8 * p;
+        const bool ft = from_T && p == 0;
         {
             ProfScope ps(c, P_RADIX_HIST);
-            k2_radix_hist<<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(kin, cntArr, B.state, B.tilehist,
-                                                                             B.S, B.TPB, shift, tiles, nbarg(nb, 8));
+            if (ft)
+                k2_radix_hist<true><<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(
+                    kin, cntArr, B.state, B.tilehist, B.S, B.TPB, shift, tiles, nbarg(nb, 8), B.T, B.present, g_r0bits);
+            else
+                k2_radix_hist<false><<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(
+                    kin, cntArr, B.state, B.tilehist, B.S, B.TPB, shift, tiles, nbarg(nb, 8), B.T, B.present, g_r0bits);
             KCHECK();
         }
         {
@@ -1366,8 +1393,14 @@ static void radix_sort5(bz2hip_ctx *c, int nb, u32 maxcnt, const u32 *cntArr, u6
         }
         {
             ProfScope ps(c, P_RADIX_SCATTER);
-            k2_radix_scatter<<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(
-                kin, kout, cntArr, B.state, B.tilehist, B.digitbase, B.S, B.TPB, shift, tiles, nbarg(nb, 8));
+            if (ft)
+                k2_radix_scatter<true><<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(
+                    kin, kout, cntArr, B.state, B.tilehist, B.digitbase, B.S, B.TPB, shift, tiles, nbarg(nb, 8),
+                    B.T, B.present, g_r0bits);
+            else
+                k2_radix_scatter<false><<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(
+                    kin, kout, cntArr, B.state, B.tilehist, B.digitbase, B.S, B.TPB, shift, tiles, nbarg(nb, 8),
+                    B.T, B.present, g_r0bits);
             KCHECK();
         }
         std::swap(kin, kout);
@@ -1405,17 +1438,12 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
     k2_reset<<<cb, 256, 0, c->stream>>>(B.n, B.present, B.mS, B.mL, B.mSn, B.mLn, B.hcur, B.huse,
                                         B.state, B.par, B.rounds, B.leftg, B.periodic, B.ctl, nb, g_r0bits);
     KCHECK();
-    {
-        ProfScope ps(c, P_BWT_INIT);
-        k2_init_keys<<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(B.T, B.n, B.present, (g_r0bits / 8) & 1 ? B.keyA : B.keyB,
-                                                                        B.S, tiles, nb, g_r0bits);
-        KCHECK();
-    }
     const int r0p = (int)g_r0bits / 8;
-    // the sorted keys must end in keyB (the L-list is rebuilt into keyA): start in keyB when the
-    // pass count is even
-    if (r0p & 1) radix_sort5(c, nb, maxn, B.n, B.keyA, B.keyB, r0p);
-    else radix_sort5(c, nb, maxn, B.n, B.keyB, B.keyA, r0p);
+    // The first pass reads the block bytes, so the keys are first written by its scatter.  The
+    // sorted keys must end in keyB (the L-list is rebuilt into keyA): with an odd pass count the
+    // passes go (T) -> keyB -> keyA -> ... -> keyB, so the "input" of pass 0 is nominally keyA.
+    if (r0p & 1) radix_sort5(c, nb, maxn, B.n, B.keyA, B.keyB, r0p, true);
+    else radix_sort5(c, nb, maxn, B.n, B.keyB, B.keyA, r0p, true);
     lrerank<MODE_ROUND0>(c, nb, maxn, B.n, ST_ACTIVE, B.keyB, B.keyA);
     bool first = true;
     int rnd = 0; // doubling rounds launched so far
@@ -1433,8 +1461,9 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
         HIPCHK(hipStreamSynchronize(c->stream));
         if (first) {
             if (c->profile) {
-                c->prof_bytes[P_RADIX_SCATTER] += r0p * 16.0 * (double)hc[8];
-                c->prof_bytes[P_RADIX_HIST] += r0p * 8.0 * (double)hc[8];
+                // pass 0 reads the block bytes (1 B) instead of 8-byte keys
+                c->prof_bytes[P_RADIX_SCATTER] += ((r0p - 1) * 16.0 + 9.0) * (double)hc[8];
+                c->prof_bytes[P_RADIX_HIST] += ((r0p - 1) * 8.0 + 1.0) * (double)hc[8];
             }
             c->st_sorted_elems += (u64)hc[8] * r0p;
             first = false;
