@@ -78,6 +78,7 @@ struct Batch {
     u64 *bitoff = nullptr;    // [2*(NB+1)] absolute bit offset of each block, then bit lengths
     u32 *pkagg = nullptr;     // [NB][S/PK_TILE] tile bit sums -> offsets
     size_t bytes = 0;
+    std::vector<void *> allocs; // device allocations of this workspace
 };
 
 struct ProfRec {
@@ -91,7 +92,16 @@ struct bz2hip_ctx {
     bz2hip_opts opts{};
     std::string err;
     Batch batch;
-    std::vector<void *> allocs;
+    // second workspace + stream: compress_core alternates batches between the two "lanes" so that
+    // MTF / Huffman of one batch run under the BWT of the next (swap_lane exchanges them)
+    Batch batch_other;
+    hipStream_t stream_other = nullptr;
+    int active_lane = 0;
+    void swap_lane() {
+        std::swap(batch, batch_other);
+        std::swap(stream, stream_other);
+        active_lane ^= 1;
+    }
     // window scratch for K1 (split / RLE1 / CRC)
     u32 *w_rs = nullptr, *w_P = nullptr, *w_agg1 = nullptr, *w_agg2 = nullptr;
     u32 *w_starts = nullptr, *w_eagg = nullptr;

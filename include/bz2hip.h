@@ -43,7 +43,7 @@ typedef struct bz2hip_ctx bz2hip_ctx;
 
 typedef struct bz2hip_opts {
     int device;            /* HIP device ordinal; -1 = current device */
-    int max_batch_blocks;  /* blocks sorted per batch (0 = default 256) */
+    int max_batch_blocks;  /* blocks sorted per batch (0 = default 1024) */
     int tie_rule;          /* origin pointer of periodic blocks (block == w^k): BZ2HIP_TIE_* */
     int profile;           /* HIP-event timing per kernel class (bz2hip_profile_*): 1 = the
                               bandwidth-bound kernels only (cheap), 2 = every class */
