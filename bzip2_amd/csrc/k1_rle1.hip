@@ -74,7 +74,8 @@ __global__ __launch_bounds__(1024) void k1_scan_tiles(u32 *__restrict__ agg, u32
 
 // per-row helper: run start of every element of the tile, wave-row layout
 // phase 3: rs[i] and tile sums of c(i)
-template <bool WRITE_P>
+// P is stored tile-local (exclusive prefix of c inside the tile); readers add the scanned tile
+// sums (agg_c) -> one pass over the input instead of two.
 __global__ __launch_bounds__(256) void k1_runs(const u8 *__restrict__ in, u32 n,
                                                const u32 *__restrict__ agg_head,
                                                u32 *__restrict__ rs, u32 *__restrict__ agg_c,
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void k1_runs(const u8 *__restrict__ in, u32 n,
         u32 c = 0;
         if (i < n) {
             u32 rsi = head ? i : (prevp1 - 1);
-            if (!WRITE_P) rs[i] = rsi;
+            rs[i] = rsi;
             if ((i - rsi + 1) % 255u == 0) c = 5;
             if (head && i > 0) c += enc_rem((i - (prevp1 - 1)) % 255u);
         }
@@ -121,45 +122,54 @@ __global__ __launch_bounds__(256) void k1_runs(const u8 *__restrict__ in, u32 n,
         if (m) carry = rowbase + (63 - __clzll((unsigned long long)m)) + 1;
     }
     wtot = wave_reduce_add(wtot);
-    if (!WRITE_P) {
-        if (lane == 0) wsum[w] = wtot;
-        __syncthreads();
-        if (threadIdx.x == 0) agg_c[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    } else {
-        if (lane == 0) wsum[w] = wtot;
-        __syncthreads();
-        u32 run = agg_c[blockIdx.x];
-        for (int q = 0; q < w; q++) run += wsum[q];
+    if (lane == 0) wsum[w] = wtot;
+    __syncthreads();
+    if (threadIdx.x == 0) agg_c[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    u32 run = 0;
+    for (int q = 0; q < w; q++) run += wsum[q];
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            u32 i = base + w * 1024 + k * 64 + lane;
-            u32 inc = wave_incl_scan_add(cv[k]);
-            if (i < n) P[i] = run + inc - cv[k];
-            run += __shfl(inc, 63, 64);
-        }
+    for (int k = 0; k < 16; k++) {
+        u32 i = base + w * 1024 + k * 64 + lane;
+        u32 inc = wave_incl_scan_add(cv[k]);
+        if (i < n) P[i] = run + inc - cv[k];
+        run += __shfl(inc, 63, 64);
     }
 }
 
-__global__ void k1_sentinels(u32 *rs, u32 *P, u32 n, const u32 *total) {
+// sentinels at position n: rs[n] = n, P(n) = total
+__global__ void k1_sentinels(u32 *rs, u32 *P, u32 *agg_c, u32 n, const u32 *total) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         rs[n] = n;
-        P[n] = *total;
+        const u32 t = n / K1_TILE;
+        if (n % K1_TILE == 0) agg_c[t] = *total; // tile n falls into does not exist yet
+        P[n] = *total - agg_c[t];
     }
 }
 
+// accessors for the two searched arrays
+struct PlainArr {
+    const u32 *a;
+    __device__ __forceinline__ u32 operator()(u32 i) const { return a[i]; }
+};
+struct PrefixArr { // absolute flushed-length prefix = tile-local value + scanned tile sum
+    const u32 *P, *agg;
+    __device__ __forceinline__ u32 operator()(u32 i) const { return P[i] + agg[i / K1_TILE]; }
+};
+
 // first i in (lo, hi] with arr[i] > thr (arr non-decreasing); returns hi+1 if none.  One wave.
-__device__ u32 wave_search_gt(const u32 *__restrict__ arr, u32 lo, u32 hi, u32 thr) {
+template <typename ARR>
+__device__ u32 wave_search_gt(const ARR arr, u32 lo, u32 hi, u32 thr) {
     const int lane = lane_id();
     if (lo >= hi) return hi + 1;
     // invariant: answer in (lo, hi] or none; first check arr[hi]
-    u32 top = arr[hi];
+    u32 top = arr(hi);
     if (!(top > thr)) return hi + 1;
     while (hi - lo > 1) {
         u32 width = hi - lo;
         u32 step = (width + 63) / 64;
         u32 idx = lo + (u32)(lane + 1) * step;
         if (idx > hi) idx = hi;
-        bool pred = arr[idx] > thr;
+        bool pred = arr(idx) > thr;
         u64 m = __ballot(pred);
         int fl = __ffsll((unsigned long long)m) - 1; // exists since arr[hi] > thr
         u32 nhi = lo + (u32)(fl + 1) * step;
@@ -173,15 +183,17 @@ __device__ u32 wave_search_gt(const u32 *__restrict__ arr, u32 lo, u32 hi, u32 t
 
 // serial chain over blocks; one wave.  starts[k] for k <= count (starts[count] = end of last).
 __global__ __launch_bounds__(64) void k1_split(const u32 *__restrict__ rs,
-                                               const u32 *__restrict__ P, u32 n, u32 block_size,
+                                               const u32 *__restrict__ Ploc,
+                                               const u32 *__restrict__ agg_c, u32 n, u32 block_size,
                                                u32 max_blocks, u32 *__restrict__ starts,
                                                u32 *__restrict__ count_out) {
     const u32 limit = block_size - 6;
+    const PrefixArr P{Ploc, agg_c};
     u32 s = 0, cnt = 0;
     while (s < n && cnt < max_blocks) {
         if (lane_id() == 0) starts[cnt] = s;
         // end of the maximal run containing s
-        u32 re0 = wave_search_gt(rs, s, n, s);
+        u32 re0 = wave_search_gt(PlainArr{rs}, s, n, s);
         if (re0 > n) re0 = n;
         u32 e;
         u32 cand = s + 255u * (limit / 5u + 1u);
@@ -199,7 +211,7 @@ __global__ __launch_bounds__(64) void k1_split(const u32 *__restrict__ rs,
             if (enc0 > limit) {
                 e = re0 + 1; // the first run alone overfills: refused right after the next head
             } else {
-                u32 thr = limit - enc0 + P[re0 + 1];
+                u32 thr = limit - enc0 + P(re0 + 1);
                 e = wave_search_gt(P, re0, hi, thr);
                 if (e > hi) e = (hi == n) ? n : hi; // not expected when hi < n
             }
@@ -434,18 +446,16 @@ u32 run_split(bz2hip_ctx *c, const u8 *d_in, u32 n, int level, u32 *d_rs, u32 *d
         KCHECK();
         k1_scan_tiles<true><<<1, 1024, 0, c->stream>>>(d_agg1, tiles, nullptr);
         KCHECK();
-        k1_runs<false><<<tiles, 256, 0, c->stream>>>(d_in, n, d_agg1, d_rs, d_agg2, nullptr);
+        k1_runs<<<tiles, 256, 0, c->stream>>>(d_in, n, d_agg1, d_rs, d_agg2, d_P);
         KCHECK();
         k1_scan_tiles<false><<<1, 1024, 0, c->stream>>>(d_agg2, tiles, B.ctl + 8);
         KCHECK();
-        k1_runs<true><<<tiles, 256, 0, c->stream>>>(d_in, n, d_agg1, nullptr, d_agg2, d_P);
-        KCHECK();
-        k1_sentinels<<<1, 64, 0, c->stream>>>(d_rs, d_P, n, B.ctl + 8);
+        k1_sentinels<<<1, 64, 0, c->stream>>>(d_rs, d_P, d_agg2, n, B.ctl + 8);
         KCHECK();
     }
     {
         ProfScope ps(c, P_RLE1_SPLIT, 0);
-        k1_split<<<1, 64, 0, c->stream>>>(d_rs, d_P, n, (u32)level * 100000u, max_blocks, d_starts,
+        k1_split<<<1, 64, 0, c->stream>>>(d_rs, d_P, d_agg2, n, (u32)level * 100000u, max_blocks, d_starts,
                                           B.ctl + 9);
         KCHECK();
     }

@@ -475,8 +475,10 @@ __device__ __forceinline__ void tile_emit(const u64 *buf, int cnt, const int (&c
         const int c = cls[k];
         u32 i = 0;
         if (c != CLS_NONE) {
-            i = (u32)(BUFX(idx) & E_IMASK);
-            if (MODE != MODE_FINAL) rank[i] = ngrp[k];
+            const u64 e_ = BUFX(idx);
+            i = (u32)(e_ & E_IMASK);
+            // the first sub-group of a split group keeps its rank: no write
+            if (MODE == MODE_ROUND0 || (MODE == MODE_NORMAL && ngrp[k] != (u32)(e_ >> 40))) rank[i] = ngrp[k];
             if (MODE == MODE_FINAL || c == CLS_SINGLE) bwt[spos[k]] = T[i == 0 ? n - 1 : i - 1];
         }
         if (MODE != MODE_FINAL) {
