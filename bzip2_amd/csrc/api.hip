@@ -91,7 +91,7 @@ static void ensure_batch(bz2hip_ctx *c, int level, int nb_needed) {
 }
 
 static void wfree(bz2hip_ctx *c) {
-    u32 **ps[] = {&c->w_rs, &c->w_P, &c->w_agg1, &c->w_agg2, &c->w_starts, &c->w_eagg};
+    u32 **ps[] = {&c->w_rs, &c->w_P, &c->w_agg1, &c->w_agg2, &c->w_starts, &c->w_eagg, &c->w_cagg};
     for (auto pp : ps) {
         if (*pp) (void)hipFree(*pp);
         *pp = nullptr;
@@ -125,8 +125,10 @@ static void ensure_window(bz2hip_ctx *c, size_t wlen, int level) {
     }
     if (c->w_eagg_nb < c->batch.NB || c->w_ETPB != ETPB) {
         if (c->w_eagg) (void)hipFree(c->w_eagg);
-        c->w_eagg = nullptr;
+        if (c->w_cagg) (void)hipFree(c->w_cagg);
+        c->w_eagg = c->w_cagg = nullptr;
         HIPCHK(hipMalloc((void **)&c->w_eagg, (size_t)c->batch.NB * ETPB * sizeof(u32)));
+        HIPCHK(hipMalloc((void **)&c->w_cagg, (size_t)c->batch.NB * ETPB * sizeof(u32)));
         c->w_eagg_nb = c->batch.NB;
         c->w_ETPB = ETPB;
     }
@@ -233,6 +235,7 @@ extern "C" void bz2hip_destroy(bz2hip_ctx *c) {
     if (c->h_out) (void)hipFree(c->h_out);
     for (auto &r : c->prof_pending) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->crc_done) (void)hipEventDestroy(c->crc_done);
     (void)hipStreamDestroy(c->stream);
     (void)hipStreamDestroy(c->stream_other);
     delete c;

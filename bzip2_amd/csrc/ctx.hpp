@@ -105,6 +105,8 @@ struct bz2hip_ctx {
     // window scratch for K1 (split / RLE1 / CRC)
     u32 *w_rs = nullptr, *w_P = nullptr, *w_agg1 = nullptr, *w_agg2 = nullptr;
     u32 *w_starts = nullptr, *w_eagg = nullptr;
+    u32 *w_cagg = nullptr;   // CRC tile partials (same shape as w_eagg; used on the other stream)
+    hipEvent_t crc_done = nullptr;
     size_t w_cap = 0;        // window capacity in input bytes
     u32 w_maxblocks = 0;
     u32 w_ETPB = 0;          // emit tiles per block slot

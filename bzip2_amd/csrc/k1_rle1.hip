@@ -475,6 +475,16 @@ void run_rle1_emit(bz2hip_ctx *c, const u8 *d_in, const u32 *d_rs, const u32 *d_
     Batch &B = c->batch;
     const u32 tiles = (max_in_len + K1_TILE - 1) / K1_TILE;
     dim3 grid(tiles, nb);
+    // The block CRCs depend only on the input and the block starts: they run on the other stream,
+    // next to the emit scan; this stream waits for them before anything that follows.
+    if (!c->crc_done) HIPCHK(hipEventCreateWithFlags(&c->crc_done, hipEventDisableTiming));
+    {
+        k1_crc_p1<<<grid, 256, 0, c->stream_other>>>(d_in, d_starts + b0, c->w_cagg, ETPB);
+        KCHECK();
+        k1_crc_p2<<<(nb + 63) / 64, 64, 0, c->stream_other>>>(d_starts + b0, c->w_cagg, B.crc, nb, ETPB);
+        KCHECK();
+        HIPCHK(hipEventRecord(c->crc_done, c->stream_other));
+    }
     {
         ProfScope ps(c, P_RLE1_EMIT, 0);
         k1_emit_p1<<<grid, 256, 0, c->stream>>>(d_in, d_rs, d_starts + b0, d_eagg, ETPB);
@@ -485,11 +495,5 @@ void run_rle1_emit(bz2hip_ctx *c, const u8 *d_in, const u32 *d_rs, const u32 *d_
                                                 B.S, ETPB);
         KCHECK();
     }
-    {
-        ProfScope ps(c, P_CRC, 0);
-        k1_crc_p1<<<grid, 256, 0, c->stream>>>(d_in, d_starts + b0, d_eagg, ETPB);
-        KCHECK();
-        k1_crc_p2<<<(nb + 63) / 64, 64, 0, c->stream>>>(d_starts + b0, d_eagg, B.crc, nb, ETPB);
-        KCHECK();
-    }
+    HIPCHK(hipStreamWaitEvent(c->stream, c->crc_done, 0));
 }
