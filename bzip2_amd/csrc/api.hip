@@ -236,6 +236,8 @@ extern "C" void bz2hip_destroy(bz2hip_ctx *c) {
     for (auto &r : c->prof_pending) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->crc_done) (void)hipEventDestroy(c->crc_done);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     (void)hipStreamDestroy(c->stream);
     (void)hipStreamDestroy(c->stream_other);
     delete c;

@@ -107,6 +107,7 @@ struct bz2hip_ctx {
     u32 *w_starts = nullptr, *w_eagg = nullptr;
     u32 *w_cagg = nullptr;   // CRC tile partials (same shape as w_eagg; used on the other stream)
     hipEvent_t crc_done = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr; // S-sort || L-path inside a doubling round
     size_t w_cap = 0;        // window capacity in input bytes
     u32 w_maxblocks = 0;
     u32 w_ETPB = 0;          // emit tiles per block slot

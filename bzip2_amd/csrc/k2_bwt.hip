@@ -1493,6 +1493,16 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
                 B.slA, B.slB, B.keyA, B.par, B.mS, B.mL, B.state, B.huse, B.n, B.rank, B.S, (mx + RTILE - 1) / RTILE, nbarg(nb, 1));
             KCHECK();
         }
+        // The S-sort and the L-path of a round touch disjoint elements (both only append to the
+        // next S-list through the atomic counter mSn): when both exist the L-path runs on the
+        // other stream.
+        const bool fork = maxS && maxL;
+        if (fork) {
+            if (!c->ev_fork) HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+            if (!c->ev_join) HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+            HIPCHK(hipEventRecord(c->ev_fork, c->stream));
+            HIPCHK(hipStreamWaitEvent(c->stream_other, c->ev_fork, 0));
+        }
         if (maxS) {
             ProfScope ps(c, P_BWT_SSORT);
             k2_ssort<MODE_NORMAL><<<xcd_grid((maxS + SC - 1) / SC, nb), RT_THREADS, 0, c->stream>>>(
@@ -1503,6 +1513,7 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
             KCHECK();
         }
         if (maxL) {
+            if (fork) std::swap(c->stream, c->stream_other); // the drivers below launch on c->stream
             {
                 // long-repeat rules on the L-list (after k2_keys, before the sort)
                 ProfScope ps(c, P_BWT_KEYS);
@@ -1521,6 +1532,11 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
             }
             radix_sort5(c, nb, maxL, B.mL, B.keyA, B.keyB);
             lrerank<MODE_NORMAL>(c, nb, maxL, B.mL, ST_ACTIVE, B.keyB, B.keyA);
+            if (fork) {
+                HIPCHK(hipEventRecord(c->ev_join, c->stream));
+                std::swap(c->stream, c->stream_other);
+                HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+            }
         }
         if (rnd == 0) {
             // the first round voted for repeat distances (S- and L-list): list their regions
