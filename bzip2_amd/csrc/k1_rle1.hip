@@ -164,17 +164,25 @@ __device__ u32 wave_search_gt(const ARR arr, u32 lo, u32 hi, u32 thr) {
     // invariant: answer in (lo, hi] or none; first check arr[hi]
     u32 top = arr(hi);
     if (!(top > thr)) return hi + 1;
+    // 256-ary steps: every lane probes 4 positions (independent loads), so a level costs one
+    // memory latency and 46 M positions need 4 levels instead of 5 (this chain is pure latency)
     while (hi - lo > 1) {
-        u32 width = hi - lo;
-        u32 step = (width + 63) / 64;
-        u32 idx = lo + (u32)(lane + 1) * step;
-        if (idx > hi) idx = hi;
-        bool pred = arr(idx) > thr;
-        u64 m = __ballot(pred);
-        int fl = __ffsll((unsigned long long)m) - 1; // exists since arr[hi] > thr
-        u32 nhi = lo + (u32)(fl + 1) * step;
-        if (nhi > hi) nhi = hi;
-        u32 nlo = lo + (u32)fl * step;
+        const u32 width = hi - lo;
+        const u32 step = (width + 255) / 256;
+        u32 best = 256; // first probe position (0..255) whose value exceeds thr
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            u32 p = (u32)lane * 4u + (u32)j;
+            u32 idx = lo + (p + 1) * step;
+            if (idx > hi || idx < lo) idx = hi;
+            bool pred = arr(idx) > thr;
+            u64 m = __ballot(pred);
+            if (m) best = min(best, (u32)(__ffsll((unsigned long long)m) - 1) * 4u + (u32)j);
+        }
+        // best < 256 always: the last probe is clamped to hi and arr(hi) > thr
+        u32 nhi = lo + (best + 1) * step;
+        if (nhi > hi || nhi < lo) nhi = hi;
+        u32 nlo = lo + best * step;
         lo = nlo;
         hi = nhi;
     }
@@ -193,7 +201,15 @@ __global__ __launch_bounds__(64) void k1_split(const u32 *__restrict__ rs,
     while (s < n && cnt < max_blocks) {
         if (lane_id() == 0) starts[cnt] = s;
         // end of the maximal run containing s
-        u32 re0 = wave_search_gt(PlainArr{rs}, s, n, s);
+        // end of the run containing s: almost always within the next 64 bytes
+        u32 re0;
+        {
+            const u32 idx = s + 1u + (u32)lane_id();
+            const bool pred = idx <= n && rs[idx] > s;
+            const u64 m = __ballot(pred);
+            if (m) re0 = s + (u32)__ffsll((unsigned long long)m);
+            else re0 = (s + 64u >= n) ? n + 1u : wave_search_gt(PlainArr{rs}, s + 64u, n, s);
+        }
         if (re0 > n) re0 = n;
         u32 e;
         u32 cand = s + 255u * (limit / 5u + 1u);
