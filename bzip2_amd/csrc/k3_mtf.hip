@@ -174,41 +174,60 @@ __global__ __launch_bounds__(64) void k3_mtf_compose(const u32 *__restrict__ nAr
     __shared__ u8 flag[256];
     ((u32 *)st)[lane] = identity_list();
     __syncthreads();
-    for (u32 c = 0; c < chunks; c++) {
-        u32 *slot = (u32 *)(mtfrec + ((size_t)b * CPB + c) * 256);
-        u32 rec = slot[lane];               // recency list of chunk c (first d entries valid)
-        const u32 d = mtfcnt[(size_t)b * CPB + c];
-        slot[lane] = ((u32 *)st)[lane];     // entry state of chunk c
-        if (c + 1 == chunks) break;
-        ((u32 *)flag)[lane] = 0;
-        __syncthreads();
+    // The walk is serial, but the recency lists do not depend on it: fetch them 8 chunks at a
+    // time (independent loads) so that a step costs LDS time, not a global-memory round trip.
+    constexpr int PF = 8;
+    for (u32 c0 = 0; c0 < chunks; c0 += PF) {
+        u32 recs[PF], ds[PF];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            u32 p = lane * 4 + k;
-            if (p < d) {
-                u8 v = (u8)(rec >> (8 * k));
-                flag[v] = 1;
-                nst[p] = v;
+        for (int q = 0; q < PF; q++) {
+            const u32 c = c0 + q;
+            recs[q] = 0;
+            ds[q] = 0;
+            if (c < chunks) {
+                recs[q] = ((const u32 *)(mtfrec + ((size_t)b * CPB + c) * 256))[lane];
+                ds[q] = mtfcnt[(size_t)b * CPB + c];
             }
         }
-        __syncthreads();
-        u32 cur = ((u32 *)st)[lane];
-        u32 keepcnt = 0;
-        bool keep[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            keep[k] = flag[(cur >> (8 * k)) & 255u] == 0;
-            keepcnt += keep[k] ? 1u : 0u;
-        }
-        u32 inc = wave_incl_scan_add(keepcnt);
-        u32 o = d + inc - keepcnt;
+        for (int q = 0; q < PF; q++) {
+            const u32 c = c0 + q;
+            if (c >= chunks) break;
+            u32 *slot = (u32 *)(mtfrec + ((size_t)b * CPB + c) * 256);
+            const u32 rec = recs[q]; // recency list of chunk c (first d entries valid)
+            const u32 d = ds[q];
+            slot[lane] = ((u32 *)st)[lane]; // entry state of chunk c
+            if (c + 1 == chunks) break;
+            ((u32 *)flag)[lane] = 0;
+            __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (keep[k]) nst[o++] = (u8)(cur >> (8 * k));
+            for (int k = 0; k < 4; k++) {
+                u32 p = lane * 4 + k;
+                if (p < d) {
+                    u8 v = (u8)(rec >> (8 * k));
+                    flag[v] = 1;
+                    nst[p] = v;
+                }
+            }
+            __syncthreads();
+            u32 cur = ((u32 *)st)[lane];
+            u32 keepcnt = 0;
+            bool keep[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                keep[k] = flag[(cur >> (8 * k)) & 255u] == 0;
+                keepcnt += keep[k] ? 1u : 0u;
+            }
+            u32 inc = wave_incl_scan_add(keepcnt);
+            u32 o = d + inc - keepcnt;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (keep[k]) nst[o++] = (u8)(cur >> (8 * k));
+            }
+            __syncthreads();
+            ((u32 *)st)[lane] = ((u32 *)nst)[lane];
+            __syncthreads();
         }
-        __syncthreads();
-        ((u32 *)st)[lane] = ((u32 *)nst)[lane];
-        __syncthreads();
     }
 }
 
