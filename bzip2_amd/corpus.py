@@ -172,6 +172,55 @@ def _thue_morse(n):
     return ((x & np.uint64(1)).astype(np.uint8) + ord("a"))
 
 
+_DEBRUIJN = {}
+
+
+def _de_bruijn_bits(order=20):
+    """Binary de Bruijn sequence B(2, order) by the prefer-one rule (2^order symbols)."""
+    if order in _DEBRUIJN:
+        return _DEBRUIJN[order]
+    size = 1 << order
+    mask = size - 1
+    seen = bytearray(size)
+    out = bytearray(size)
+    w = 0
+    seen[0] = 1
+    k = 0
+    # the sequence starts with `order` zeros (window 0 is taken); greedy: append 1 if new, else 0
+    while k < size:
+        w1 = ((w << 1) | 1) & mask
+        if not seen[w1]:
+            seen[w1] = 1
+            w = w1
+            out[k] = 1
+        else:
+            w0 = (w << 1) & mask
+            if seen[w0]:
+                break
+            seen[w0] = 1
+            w = w0
+            out[k] = 0
+        k += 1
+    res = np.frombuffer(bytes(out[:k]), dtype=np.uint8).copy()
+    _DEBRUIJN[order] = res
+    return res
+
+
+def square_block(level=9, seed=7):
+    """Input whose first block at `level` is exactly w^2 (len(w) = (bs - 4) / 2, run-free), followed
+    by unrelated data (SURVEY config 5: a block that is w^k with len(w) = 449 998, k = 2)."""
+    rng = np.random.default_rng(seed)
+    half = (level * 100000 - 4) // 2
+    w = rng.integers(0, 255, half, dtype=np.uint8)
+    # no byte four times in a row (RLE1 must be the identity) and no run across the seam
+    for i in range(1, half):
+        if w[i] == w[i - 1]:
+            w[i] = (int(w[i]) + 1) % 255
+    if w[0] == w[-1]:
+        w[0] = (int(w[0]) + 2) % 255 if (int(w[0]) + 2) % 255 != w[1] else (int(w[0]) + 3) % 255
+    return np.concatenate((w, w, rng.integers(0, 256, 5000, dtype=np.uint8)))
+
+
 def adversarial(n=250000, seed=99):
     """Adversarial inputs at a size the CPU oracle handles in seconds."""
     rng = np.random.default_rng(seed)
@@ -201,4 +250,6 @@ def adversarial(n=250000, seed=99):
     out["sparse2"] = (rng.random(n) < 0.01).astype(np.uint8) + ord("0")
     half = rng.integers(0, 256, n // 2, dtype=np.uint8)
     out["square"] = np.concatenate((half, half))
+    db = _de_bruijn_bits(20)
+    out["debruijn"] = (np.resize(db, n) + ord("0")).astype(np.uint8)
     return out

@@ -160,6 +160,7 @@ def _periodic_inputs():
         "w1000": np.tile(rng.integers(0, 256, 1000, dtype=np.uint8), 99),
         "w33333^3": np.tile(rng.integers(0, 256, 33333, dtype=np.uint8), 3),
         "abc33": np.tile(np.frombuffer(b"abc", dtype=np.uint8), 33),
+        "w449998^2+tail": corpus.square_block(9),                    # first -9 block is exactly w^2
         "same3": np.full(3, 65, dtype=np.uint8),
         "zeros4": np.zeros(4, dtype=np.uint8),                       # RLE1 -> five zero bytes
     }
