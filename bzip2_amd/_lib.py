@@ -21,7 +21,7 @@ SYMBOLS = [
     "bz2hip_compress_blocks_device", "bz2hip_compress_blocks", "bz2hip_stitch",
     "bz2hip_stream_begin", "bz2hip_stream_write", "bz2hip_stream_finish", "bz2hip_stream_read",
     "bz2hip_stream_pending", "bz2hip_rle1_split", "bz2hip_bwt", "bz2hip_mtf_rle2",
-    "bz2hip_huffman", "bz2hip_block_compress", "bz2hip_profile_reset", "bz2hip_profile_get",
+    "bz2hip_huffman", "bz2hip_block_compress", "bz2hip_profile_reset", "bz2hip_profile_get", "bz2hip_last_stats3",
     "bz2hip_last_stats", "bz2hip_last_stats2",
 ]
 
@@ -98,6 +98,8 @@ def load():
     L.bz2hip_last_stats.argtypes = [vp, vp, vp, vp, vp]
     L.bz2hip_last_stats2.restype = C.c_int
     L.bz2hip_last_stats2.argtypes = [vp, vp, vp]
+    L.bz2hip_last_stats3.restype = C.c_int
+    L.bz2hip_last_stats3.argtypes = [vp, vp, vp]
     _lib = L
     return L
 
@@ -331,6 +333,9 @@ class Context:
         self.L.bz2hip_last_stats(self.h, *[C.byref(x) for x in v])
         w = [C.c_uint64(0), C.c_uint64(0)]
         self.L.bz2hip_last_stats2(self.h, C.byref(w[0]), C.byref(w[1]))
+        secs = C.c_double(0.0)
+        traps = C.c_uint64(0)
+        self.L.bz2hip_last_stats3(self.h, C.byref(secs), C.byref(traps))
         return {"blocks": v[0].value, "rounds_sum": v[1].value, "rle_bytes": v[2].value,
                 "periodic_blocks": v[3].value, "n_times_rounds": w[0].value,
-                "sorted_elems": w[1].value}
+                "sorted_elems": w[1].value, "bwt_seconds": secs.value, "tie_traps": traps.value}

@@ -2,6 +2,7 @@
 #include "ctx.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 
 // Larger batches are faster (768 MiB: 6.9 GB/s at 256 blocks per batch, 7.5 GB/s at 384+); a
@@ -258,6 +259,8 @@ static size_t compress_core(bz2hip_ctx *c, const u8 *d_in, size_t n, int level, 
     bool wrote_header = !header;
     c->st_blocks = c->st_rounds = c->st_rle_bytes = c->st_periodic = 0;
     c->st_sorted_elems = c->st_nr = c->st_s_elems = 0;
+    c->st_bwt_seconds = 0;
+    c->st_tie_traps = 0;
     std::vector<u32> starts;
     bool any_frame = false;
     while (pos < n) {
@@ -798,6 +801,13 @@ extern "C" int bz2hip_last_stats2(bz2hip_ctx *c, uint64_t *n_times_rounds, uint6
     if (!c) return BZ2HIP_E_PARAM;
     if (n_times_rounds) *n_times_rounds = c->st_nr;
     if (sorted_elems) *sorted_elems = c->st_sorted_elems;
+    return BZ2HIP_OK;
+}
+
+extern "C" int bz2hip_last_stats3(bz2hip_ctx *c, double *bwt_seconds, uint64_t *tie_traps) {
+    if (!c) return BZ2HIP_E_PARAM;
+    if (bwt_seconds) *bwt_seconds = c->st_bwt_seconds;
+    if (tie_traps) *tie_traps = c->st_tie_traps;
     return BZ2HIP_OK;
 }
 

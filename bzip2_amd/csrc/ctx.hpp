@@ -125,6 +125,7 @@ struct bz2hip_ctx {
     double prof_bytes[P_COUNT] = {0};
     // stats of the last call
     u64 st_blocks = 0, st_rounds = 0, st_rle_bytes = 0, st_periodic = 0;
+    double st_bwt_seconds = 0;
     u64 st_tie_traps = 0; // periodic blocks on which the reference would have indexed past its array
     u64 st_s_elems = 0;      // elements sorted by the LDS (S) path, summed over rounds
     u64 st_sorted_elems = 0; // sum over radix passes of elements moved

@@ -19,6 +19,8 @@
 // LSD pass = tile digit histogram (LDS atomics) -> per-block scan -> stable scatter (wave64
 // ballot matching, per-wave LDS counters).  HBM-bound; no MFMA.
 #include "ctx.hpp"
+
+#include <chrono>
 #include <climits>
 
 #define GS 1024          // largest group the S-path takes
@@ -1432,6 +1434,7 @@ static void lrerank(bz2hip_ctx *c, int nb, u32 maxcnt, const u32 *cntArr, u32 wa
 void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
     Batch &B = c->batch;
     if (nb == 0 || maxn == 0) return;
+    const auto t_begin = std::chrono::steady_clock::now();
     if (const char *pm = getenv("BZ2HIP_PLAIN")) g_plain_mask = (u32)atoi(pm);
     if (const char *pm = getenv("BZ2HIP_R0BITS")) g_r0bits = (u32)atoi(pm);
     const u32 tiles = (maxn + RTILE - 1) / RTILE;
@@ -1549,6 +1552,8 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
         }
         rnd++;
     }
+    // the loop above ended on a device round trip: everything but the tie flush below has run
+    c->st_bwt_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     if (anyfin) {
         // periodic blocks: flush the k-fold ties in list order
         if (finS) {

@@ -156,6 +156,11 @@ int bz2hip_last_stats(bz2hip_ctx *ctx, uint64_t *blocks, uint64_t *rounds_sum,
 /* sum over blocks of n_b * rounds_b, and elements moved summed over all radix passes */
 int bz2hip_last_stats2(bz2hip_ctx *ctx, uint64_t *n_times_rounds, uint64_t *sorted_elems);
 
+/* host wall-clock seconds the last call spent driving the BWT stage (its round loop ends with a
+ * device round trip, so this is the stage's elapsed time), and the number of periodic blocks on
+ * which the reference's sorter would have indexed past its work array */
+int bz2hip_last_stats3(bz2hip_ctx *ctx, double *bwt_seconds, uint64_t *tie_traps);
+
 #ifdef __cplusplus
 }
 #endif
