@@ -209,15 +209,20 @@ __global__ __launch_bounds__(256) void k2_radix_scan(const u32 *__restrict__ cnt
     digitbase[b * 256 + threadIdx.x] = ex;
 }
 
+// Lanes holding the same 8-bit digit (stable ranking inside a wave).  Per bit: t = -bit (one
+// v_bfe_i32), one ballot, and "lanes that differ from me in this bit" = ballot ^ t, OR-ed up;
+// the complement of the union is the match set.
 __device__ __forceinline__ u64 match8(u32 d, bool valid) {
-    u64 m = __ballot(valid);
+    u32 acc_lo = 0, acc_hi = 0;
 #pragma unroll
     for (int bit = 0; bit < 8; bit++) {
-        bool s = (d >> bit) & 1;
-        u64 bb = __ballot(s);
-        m &= s ? bb : ~bb;
+        const int t = __builtin_amdgcn_sbfe((int)d, bit, 1); // 0 or -1
+        const u64 bb = __ballot(t != 0);
+        acc_lo |= (u32)bb ^ (u32)t;
+        acc_hi |= (u32)(bb >> 32) ^ (u32)t;
     }
-    return m;
+    const u64 v = __ballot(valid);
+    return ~(((u64)acc_hi << 32) | (u64)acc_lo) & v;
 }
 
 template <bool FROM_T>
@@ -247,12 +252,19 @@ __global__ __launch_bounds__(RT_THREADS) void k2_radix_scatter(
     u64 keys[RT_ITEMS];
     u32 lr[RT_ITEMS];
     const u64 lt = (1ull << lane) - 1ull;
+    // all 16 loads first (clamped address instead of a branch, so that they are issued back to
+    // back and the ranking below does not wait for memory once per row)
+#pragma unroll
+    for (int k = 0; k < RT_ITEMS; k++) {
+        const u32 i = base + w * (RTILE / 4) + k * 64 + lane;
+        const u32 ic = i < n ? i : base; // base < n
+        keys[k] = FROM_T ? r0_key(L, ic - base, ic, d0) : __builtin_nontemporal_load(&kp[ic]);
+    }
 #pragma unroll
     for (int k = 0; k < RT_ITEMS; k++) {
         u32 i = base + w * (RTILE / 4) + k * 64 + lane;
         bool valid = i < n;
-        u64 kk = 0;
-        if (valid) kk = FROM_T ? r0_key(L, i - base, i, d0) : __builtin_nontemporal_load(&kp[i]);
+        u64 kk = valid ? keys[k] : 0;
         keys[k] = kk;
         u32 d = (u32)(kk >> shift) & 255u;
         u64 m = match8(d, valid);
