@@ -172,17 +172,16 @@ __global__ __launch_bounds__(RT_THREADS) void k2_radix_hist(const u64 *__restric
     const u64 *kp = key + (size_t)b * S;
     typedef u64 u64x2 __attribute__((ext_vector_type(2)));
     const u64x2 *kp2 = (const u64x2 *)(kp + base); // base is a multiple of 4096: 16-byte aligned
+    // the block slot is padded (S >= n + 8 and a multiple of the tile), so whole pairs can be
+    // read unconditionally; all 8 loads are issued before the first LDS atomic
+    u64x2 vv[RT_ITEMS / 2];
+#pragma unroll
+    for (int k = 0; k < RT_ITEMS / 2; k++) vv[k] = __builtin_nontemporal_load(&kp2[k * RT_THREADS + threadIdx.x]);
 #pragma unroll
     for (int k = 0; k < RT_ITEMS / 2; k++) {
-        const u32 q = k * RT_THREADS + threadIdx.x; // pair index inside the tile
-        const u32 i = base + 2 * q;
-        if (i + 1 < n) {
-            const u64x2 v = __builtin_nontemporal_load(&kp2[q]);
-            atomicAdd(&hist[(u32)(v.x >> shift) & 255u], 1u);
-            atomicAdd(&hist[(u32)(v.y >> shift) & 255u], 1u);
-        } else if (i < n) {
-            atomicAdd(&hist[(u32)(kp[i] >> shift) & 255u], 1u);
-        }
+        const u32 i = base + 2 * (k * RT_THREADS + threadIdx.x);
+        if (i < n) atomicAdd(&hist[(u32)(vv[k].x >> shift) & 255u], 1u);
+        if (i + 1 < n) atomicAdd(&hist[(u32)(vv[k].y >> shift) & 255u], 1u);
     }
     __syncthreads();
     tilehist[((size_t)b * TPB + bz_t) * 256 + threadIdx.x] = hist[threadIdx.x];
@@ -325,16 +324,25 @@ __global__ __launch_bounds__(RT_THREADS) void k2_keys(u64 *__restrict__ slA, u64
     u64 *list = (zsel ? keyA : (par[b] ? slB : slA)) + (size_t)b * S;
     const u32 n = nArr[b], h = huse[b];
     const u32 *rk = rank + (size_t)b * S;
-#pragma unroll 4
+    // three unconditional phases (clamped addresses) so that the 16 loads, then the 16 gathers,
+    // are in flight together instead of one dependent load-gather-store chain per element
+    u64 ev[RT_ITEMS];
+    u32 rv[RT_ITEMS];
+#pragma unroll
     for (int k = 0; k < RT_ITEMS; k++) {
-        u32 j = base + k * RT_THREADS + threadIdx.x;
-        if (j < m) {
-            u64 e = list[j];
-            u32 i = (u32)(e & E_IMASK);
-            u32 i2 = i + h;
-            if (i2 >= n) i2 -= n;
-            list[j] = e | ((u64)rk[i2] << KEY_SHIFT);
-        }
+        const u32 j = base + k * RT_THREADS + threadIdx.x;
+        ev[k] = list[j < m ? j : base];
+    }
+#pragma unroll
+    for (int k = 0; k < RT_ITEMS; k++) {
+        u32 i2 = (u32)(ev[k] & E_IMASK) + h;
+        if (i2 >= n) i2 -= n;
+        rv[k] = rk[i2];
+    }
+#pragma unroll
+    for (int k = 0; k < RT_ITEMS; k++) {
+        const u32 j = base + k * RT_THREADS + threadIdx.x;
+        if (j < m) list[j] = ev[k] | ((u64)rv[k] << KEY_SHIFT);
     }
 }
 
@@ -483,6 +491,20 @@ __device__ __forceinline__ void tile_emit(const u64 *buf, int cnt, const int (&c
             lRun += (u32)sm[4 + q];
         }
     }
+    // gather the preceding bytes of all finished rotations first (16 gathers in flight; the
+    // others read T[0]), then do the stores
+    u8 tb[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int idx = w * 1024 + k * 64 + lane;
+        const int c = cls[k];
+        u32 a = 0;
+        if (c != CLS_NONE && (MODE == MODE_FINAL || c == CLS_SINGLE)) {
+            const u32 i = (u32)(BUFX(idx) & E_IMASK);
+            a = (i == 0) ? n - 1 : i - 1;
+        }
+        tb[k] = T[a];
+    }
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         const int idx = w * 1024 + k * 64 + lane;
@@ -493,7 +515,7 @@ __device__ __forceinline__ void tile_emit(const u64 *buf, int cnt, const int (&c
             i = (u32)(e_ & E_IMASK);
             // the first sub-group of a split group keeps its rank: no write
             if (MODE == MODE_ROUND0 || (MODE == MODE_NORMAL && ngrp[k] != (u32)(e_ >> 40))) rank[i] = ngrp[k];
-            if (MODE == MODE_FINAL || c == CLS_SINGLE) bwt[spos[k]] = T[i == 0 ? n - 1 : i - 1];
+            if (MODE == MODE_FINAL || c == CLS_SINGLE) bwt[spos[k]] = tb[k];
         }
         if (MODE != MODE_FINAL) {
             u64 ms = __ballot(c == CLS_SMALL), ml = __ballot(c == CLS_LKEEP);
@@ -524,7 +546,17 @@ __global__ __launch_bounds__(RT_THREADS) void k2_lrerank_p1(const u64 *__restric
     __shared__ int sm[16];
     const u64 *kp = key + (size_t)b * S;
     const int cnt = (int)min((u32)RTILE, m - base);
-    for (int q = threadIdx.x; q < RTILE; q += RT_THREADS) buf[q] = (q < cnt) ? __builtin_nontemporal_load(&kp[base + q]) : ~0ull;
+    {
+        // the slot is padded to whole tiles: read the tile unconditionally, 16 loads in flight
+        u64 tmp[RT_ITEMS];
+#pragma unroll
+        for (int k = 0; k < RT_ITEMS; k++) tmp[k] = __builtin_nontemporal_load(&kp[base + k * RT_THREADS + threadIdx.x]);
+#pragma unroll
+        for (int k = 0; k < RT_ITEMS; k++) {
+            const int q = k * RT_THREADS + threadIdx.x;
+            buf[q] = (q < cnt) ? tmp[k] : ~0ull;
+        }
+    }
     const bool has_prev = base > 0;
     const u64 prevE = has_prev ? kp[base - 1] : 0;
     bool end_head = true;
@@ -619,7 +651,17 @@ __global__ __launch_bounds__(RT_THREADS) void k2_lrerank_p3(
     __shared__ int sm[16];
     const u64 *kp = key + (size_t)b * S;
     const int cnt = (int)min((u32)RTILE, m - base);
-    for (int q = threadIdx.x; q < RTILE; q += RT_THREADS) buf[q] = (q < cnt) ? __builtin_nontemporal_load(&kp[base + q]) : ~0ull;
+    {
+        // the slot is padded to whole tiles: read the tile unconditionally, 16 loads in flight
+        u64 tmp[RT_ITEMS];
+#pragma unroll
+        for (int k = 0; k < RT_ITEMS; k++) tmp[k] = __builtin_nontemporal_load(&kp[base + k * RT_THREADS + threadIdx.x]);
+#pragma unroll
+        for (int k = 0; k < RT_ITEMS; k++) {
+            const int q = k * RT_THREADS + threadIdx.x;
+            buf[q] = (q < cnt) ? tmp[k] : ~0ull;
+        }
+    }
     const bool has_prev = base > 0;
     const u64 prevE = has_prev ? kp[base - 1] : 0;
     bool end_head = true;
@@ -884,18 +926,26 @@ __device__ __forceinline__ bool lap_qualifies(u32 gf) {
     u64 ev[RT_ITEMS];                                                                           \
     u32 fl[RT_ITEMS];                                                                           \
     u64 hm[RT_ITEMS];                                                                           \
+    u64 e1[RT_ITEMS], e2[RT_ITEMS];                                                             \
+    _Pragma("unroll") for (int k = 0; k < RT_ITEMS; k++) {                                      \
+        const u32 j = base + (u32)(w * 1024 + k * 64 + lane);                                   \
+        const u32 jc = j < m ? j : base;                                                        \
+        ev[k] = list[jc];                                                                       \
+        e1[k] = list[jc >= 1 ? jc - 1 : 0];                                                     \
+        e2[k] = list[jc >= 2 ? jc - 2 : 0];                                                     \
+    }                                                                                           \
     _Pragma("unroll") for (int k = 0; k < RT_ITEMS; k++) {                                      \
         const u32 j = base + (u32)(w * 1024 + k * 64 + lane);                                   \
         bool head = false;                                                                      \
         u32 f = 0;                                                                              \
         u64 e = 0;                                                                              \
         if (j < m) {                                                                            \
-            e = list[j];                                                                        \
+            e = ev[k];                                                                          \
             if (j == 0) head = true;                                                            \
             else {                                                                              \
-                const u64 ep = list[j - 1];                                                     \
+                const u64 ep = e1[k];                                                           \
                 head = (e >> 40) != (ep >> 40);                                                 \
-                if (!head) f = lap_pair_flags(e, ep, j >= 2, j >= 2 ? list[j - 2] : 0ull, hcur, s_runs); \
+                if (!head) f = lap_pair_flags(e, ep, j >= 2, e2[k], hcur, s_runs);              \
             }                                                                                   \
         }                                                                                       \
         ev[k] = e;                                                                              \
@@ -1136,19 +1186,35 @@ __global__ __launch_bounds__(RT_THREADS, 3) void k2_ssort(const u64 *slA, const 
     __syncthreads();
     // load window, find owned span: groups whose head slot is in [t0, t0 + SC)
     int myStart = CROSS, myEnd = CROSS;
-    for (int q = threadIdx.x; q < RTILE; q += RT_THREADS) {
-        u64 e = ~0ull;
-        if (q < loaded) {
-            e = __builtin_nontemporal_load(&in[t0 + q]);
-            bool head;
-            if (q == 0) head = (t0 == 0) || ((e >> 40) != (in[t0 - 1] >> 40));
-            else head = (e >> 40) != (in[t0 + q - 1] >> 40);
-            if (head) {
-                if (q < SC) myStart = min(myStart, q);
-                else myEnd = min(myEnd, q);
+    {
+        // 16 window loads in flight (clamped: the window may reach past the slot), then the
+        // head test against the left neighbour through LDS
+        u64 tmp[RT_ITEMS];
+#pragma unroll
+        for (int k = 0; k < RT_ITEMS; k++) {
+            const int q = k * RT_THREADS + threadIdx.x;
+            tmp[k] = __builtin_nontemporal_load(&in[t0 + (q < loaded ? q : 0)]);
+        }
+        const u64 left = t0 ? in[t0 - 1] : 0ull;
+#pragma unroll
+        for (int k = 0; k < RT_ITEMS; k++) {
+            const int q = k * RT_THREADS + threadIdx.x;
+            buf[SZ(q)] = (q < loaded) ? tmp[k] : ~0ull;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < RT_ITEMS; k++) {
+            const int q = k * RT_THREADS + threadIdx.x;
+            if (q < loaded) {
+                bool head;
+                if (q == 0) head = (t0 == 0) || ((tmp[k] >> 40) != (left >> 40));
+                else head = (tmp[k] >> 40) != (buf[SZ(q - 1)] >> 40);
+                if (head) {
+                    if (q < SC) myStart = min(myStart, q);
+                    else myEnd = min(myEnd, q);
+                }
             }
         }
-        buf[SZ(q)] = e;
     }
     if (myStart != CROSS) atomicMin(&s_start, myStart);
     if (myEnd != CROSS) atomicMin(&s_end, myEnd);
