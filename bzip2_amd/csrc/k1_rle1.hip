@@ -29,13 +29,19 @@ __global__ __launch_bounds__(256) void k1_heads_p1(const u8 *__restrict__ in, u3
     const u32 base = blockIdx.x * K1_TILE;
     __shared__ u32 sm[8];
     u32 last = 0;
-#pragma unroll 4
+    // unconditional (clamped) loads first: 32 byte loads in flight per thread
+    u8 c0[16], c1[16];
+#pragma unroll
     for (int k = 0; k < 16; k++) {
-        u32 i = base + k * 256 + threadIdx.x;
-        if (i < n) {
-            bool head = (i == 0) || (in[i] != in[i - 1]);
-            if (head) last = i + 1;
-        }
+        const u32 i = base + k * 256 + threadIdx.x;
+        const u32 ic = i < n ? i : n - 1;
+        c0[k] = in[ic];
+        c1[k] = in[ic ? ic - 1 : 0];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const u32 i = base + k * 256 + threadIdx.x;
+        if (i < n && (i == 0 || c0[k] != c1[k])) last = i + 1;
     }
     u32 t = block_reduce_max<256>(last, sm);
     if (threadIdx.x == 0) agg[blockIdx.x] = t;
@@ -86,11 +92,19 @@ __global__ __launch_bounds__(256) void k1_runs(const u8 *__restrict__ in, u32 n,
     __shared__ u32 wsum[4];
     u64 hm[16];
     u32 last = 0;
+    u8 c0[16], c1[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const u32 i = base + w * 1024 + k * 64 + lane;
+        const u32 ic = i < n ? i : n - 1;
+        c0[k] = in[ic];
+        c1[k] = in[ic ? ic - 1 : 0];
+    }
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         u32 i = base + w * 1024 + k * 64 + lane;
         bool head = false;
-        if (i < n) head = (i == 0) || (in[i] != in[i - 1]);
+        if (i < n) head = (i == 0) || (c0[k] != c1[k]);
         u64 m = __ballot(head);
         hm[k] = m;
         if (m) last = base + w * 1024 + k * 64 + (63 - __clzll((unsigned long long)m)) + 1;
@@ -255,6 +269,18 @@ __device__ __forceinline__ u32 emit_count(const u8 *__restrict__ in, const u32 *
     return (k < 4u ? 1u : 0u) + (hc ? 1u : 0u);
 }
 
+// same with the three inputs already loaded (r0 = rs[i], cur = in[i], nxt = in[i + 1])
+__device__ __forceinline__ u32 emit_count_v(u32 r0, u8 cur, u8 nxt, u32 s, u32 e, u32 i,
+                                            u32 *count_byte, bool *has_count) {
+    if (r0 < s) r0 = s;
+    u32 k = (i - r0) % 255u;
+    bool chunk_end = (k == 254u) || (i + 1 == e) || (nxt != cur);
+    bool hc = chunk_end && k >= 3u;
+    *has_count = hc;
+    *count_byte = k - 3u;
+    return (k < 4u ? 1u : 0u) + (hc ? 1u : 0u);
+}
+
 __global__ __launch_bounds__(256) void k1_emit_p1(const u8 *__restrict__ in,
                                                   const u32 *__restrict__ rs,
                                                   const u32 *__restrict__ starts,
@@ -265,13 +291,23 @@ __global__ __launch_bounds__(256) void k1_emit_p1(const u8 *__restrict__ in,
     if (base >= e) return;
     __shared__ u32 sm[8];
     u32 tot = 0;
-#pragma unroll 4
+    u32 rv[16];
+    u8 cur[16], nxt[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const u32 i = base + k * 256 + threadIdx.x;
+        const u32 ic = i < e ? i : e - 1;
+        rv[k] = rs[ic];
+        cur[k] = in[ic];
+        nxt[k] = in[ic + 1 < e ? ic + 1 : e - 1];
+    }
+#pragma unroll
     for (int k = 0; k < 16; k++) {
         u32 i = base + k * 256 + threadIdx.x;
         if (i < e) {
             u32 cb;
             bool hc;
-            tot += emit_count(in, rs, s, e, i, &cb, &hc);
+            tot += emit_count_v(rv[k], cur[k], nxt[k], s, e, i, &cb, &hc);
         }
     }
     u32 t = block_reduce_add<256>(tot, sm);
@@ -314,12 +350,22 @@ __global__ __launch_bounds__(256) void k1_emit_p3(const u8 *__restrict__ in,
     if (threadIdx.x < 8) pres[threadIdx.x] = 0;
     u32 ec[16], cbv[16];
     u32 wtot = 0;
+    u32 rv[16];
+    u8 cur[16], nxt[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const u32 i = base + w * 1024 + k * 64 + lane;
+        const u32 ic = i < e ? i : e - 1;
+        rv[k] = rs[ic];
+        cur[k] = in[ic];
+        nxt[k] = in[ic + 1 < e ? ic + 1 : e - 1];
+    }
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         u32 i = base + w * 1024 + k * 64 + lane;
         u32 c = 0, cb = 0;
         bool hc = false;
-        if (i < e) c = emit_count(in, rs, s, e, i, &cb, &hc);
+        if (i < e) c = emit_count_v(rv[k], cur[k], nxt[k], s, e, i, &cb, &hc);
         ec[k] = c;
         cbv[k] = hc ? cb : 0xffffffffu;
         wtot += c;
@@ -332,13 +378,12 @@ __global__ __launch_bounds__(256) void k1_emit_p3(const u8 *__restrict__ in,
     u8 *out = T + (size_t)b * S;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        u32 i = base + w * 1024 + k * 64 + lane;
         u32 c = ec[k];
         u32 inc = wave_incl_scan_add(c);
         u32 o = run + inc - c;
         run += __shfl(inc, 63, 64);
         if (c) {
-            u8 v = in[i];
+            u8 v = cur[k];
             bool hc = cbv[k] != 0xffffffffu;
             if (c == 2 || !hc) { // the data byte itself is emitted
                 out[o++] = v;

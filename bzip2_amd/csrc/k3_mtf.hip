@@ -250,11 +250,15 @@ __global__ __launch_bounds__(256) void k3_rle2_p1(const u8 *__restrict__ mtfpos,
     // per wave: rows of 64 elements in its 1024-element range
     u32 first = 0xffffffffu, last = 0; // position+1 of last non-zero seen (0 = none)
     u32 inner = 0;
-#pragma unroll 4
+    // the slot is padded to whole tiles: 16 unconditional loads in flight
+    u8 pv[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) pv[k] = mp[base + w * 1024 + k * 64 + lane];
+#pragma unroll
     for (int k = 0; k < 16; k++) {
         u32 rowbase = base + w * 1024 + k * 64;
         u32 j = rowbase + lane;
-        bool nz = (j < end) && (j == n || mp[j] != 0);
+        bool nz = (j < end) && (j == n || pv[k] != 0);
         u64 m = __ballot(nz);
         if (m == 0) continue;
         // previous non-zero for this lane: inside row, else `last`
@@ -368,12 +372,15 @@ __global__ __launch_bounds__(256) void k3_rle2_p3(const u8 *__restrict__ mtfpos,
     u64 hm[16];
     u32 myv[16];
     u32 first = 0xffffffffu, last = 0;
+    u8 pv[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) pv[k] = mp[base + w * 1024 + k * 64 + lane];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         u32 rowbase = base + w * 1024 + k * 64;
         u32 j = rowbase + lane;
         u32 v = 0;
-        if (j < end) v = (j == n) ? 0xffffu : mp[j];
+        if (j < end) v = (j == n) ? 0xffffu : pv[k];
         myv[k] = v;
         u64 m = __ballot(v != 0);
         hm[k] = m;
