@@ -81,9 +81,17 @@ __global__ __launch_bounds__(256) void k3_mtf_chunks(const u8 *__restrict__ bwt,
     u32 seen = 0;
     u32 prev = 0xffffffffu;
     const u32 cend = min(cbase + MTF_CHUNK, n);
-    for (u32 rowbase = cbase; rowbase < cend; rowbase += 64) {
+    // the chunk's 16 rows are fetched up front (the slot is padded to whole chunks), so the serial
+    // walk below never waits for memory
+    u8 rowv[MTF_CHUNK / 64];
+#pragma unroll
+    for (int r = 0; r < MTF_CHUNK / 64; r++) rowv[r] = src[cbase + r * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < MTF_CHUNK / 64; r++) {
+        const u32 rowbase = cbase + r * 64;
+        if (rowbase >= cend) break;
         u32 j = rowbase + lane;
-        u32 sym = (j < cend) ? smap[src[j]] : 0;
+        u32 sym = (j < cend) ? smap[rowv[r]] : 0;
         u32 mypos = 0;
         // only run heads move the list (a repeated symbol is at position 0): visit set bits only
         u32 left = (u32)__builtin_amdgcn_update_dpp((int)prev, (int)sym, 0x138, 0xf, 0xf, false);
@@ -133,7 +141,16 @@ __global__ __launch_bounds__(256) void k3_mtf_recency(const u8 *__restrict__ bwt
     if (cbase >= n) return;
     const u32 cend = min(cbase + MTF_CHUNK, n);
     const u8 *src = bwt + (size_t)b * S;
-    for (u32 j = cbase + lane; j < cend; j += 64) atomicMax(&last[w][smap[src[j]]], j - cbase + 1);
+    {
+        u8 rowv[MTF_CHUNK / 64];
+#pragma unroll
+        for (int r = 0; r < MTF_CHUNK / 64; r++) rowv[r] = src[cbase + r * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < MTF_CHUNK / 64; r++) {
+            const u32 j = cbase + r * 64 + lane;
+            if (j < cend) atomicMax(&last[w][smap[rowv[r]]], j - cbase + 1);
+        }
+    }
     // wave-local: LDS operations of one wave complete in order
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
