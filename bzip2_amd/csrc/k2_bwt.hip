@@ -324,25 +324,29 @@ __global__ __launch_bounds__(RT_THREADS) void k2_keys(u64 *__restrict__ slA, u64
     u64 *list = (zsel ? keyA : (par[b] ? slB : slA)) + (size_t)b * S;
     const u32 n = nArr[b], h = huse[b];
     const u32 *rk = rank + (size_t)b * S;
-    // three unconditional phases (clamped addresses) so that the 16 loads, then the 16 gathers,
-    // are in flight together instead of one dependent load-gather-store chain per element
-    u64 ev[RT_ITEMS];
-    u32 rv[RT_ITEMS];
+    // unconditional phases (clamped addresses) so that 8 loads, then 8 gathers, are in flight
+    // together instead of one dependent load-gather-store chain per element; two halves keep the
+    // register count low enough for 8 waves per SIMD
 #pragma unroll
-    for (int k = 0; k < RT_ITEMS; k++) {
-        const u32 j = base + k * RT_THREADS + threadIdx.x;
-        ev[k] = list[j < m ? j : base];
-    }
+    for (int half = 0; half < 2; half++) {
+        u64 ev[RT_ITEMS / 2];
+        u32 rv[RT_ITEMS / 2];
 #pragma unroll
-    for (int k = 0; k < RT_ITEMS; k++) {
-        u32 i2 = (u32)(ev[k] & E_IMASK) + h;
-        if (i2 >= n) i2 -= n;
-        rv[k] = rk[i2];
-    }
+        for (int k = 0; k < RT_ITEMS / 2; k++) {
+            const u32 j = base + (half * (RT_ITEMS / 2) + k) * RT_THREADS + threadIdx.x;
+            ev[k] = list[j < m ? j : base];
+        }
 #pragma unroll
-    for (int k = 0; k < RT_ITEMS; k++) {
-        const u32 j = base + k * RT_THREADS + threadIdx.x;
-        if (j < m) list[j] = ev[k] | ((u64)rv[k] << KEY_SHIFT);
+        for (int k = 0; k < RT_ITEMS / 2; k++) {
+            u32 i2 = (u32)(ev[k] & E_IMASK) + h;
+            if (i2 >= n) i2 -= n;
+            rv[k] = rk[i2];
+        }
+#pragma unroll
+        for (int k = 0; k < RT_ITEMS / 2; k++) {
+            const u32 j = base + (half * (RT_ITEMS / 2) + k) * RT_THREADS + threadIdx.x;
+            if (j < m) list[j] = ev[k] | ((u64)rv[k] << KEY_SHIFT);
+        }
     }
 }
 
