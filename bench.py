@@ -25,8 +25,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--segments", type=int, default=256, help="1 MiB segments per GPU")
     ap.add_argument("--level", type=int, default=9)
     ap.add_argument("--batch", type=int, default=0, help="blocks per batch (0 = library default)")
@@ -149,7 +149,9 @@ def main():
             try:
                 with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
                     pmc = json.load(f)
-                pmc_name = {"k2_ssort": "void k2_ssort<0>", "k3_mtf_chunks<true>": "void k3_mtf_chunks<true>"}
+                pmc_name = {"k2_ssort": "void k2_ssort<0>", "k3_mtf_chunks<true>": "void k3_mtf_chunks<true>",
+                            "k2_radix_scatter": "void k2_radix_scatter<false>",
+                            "k2_radix_hist": "void k2_radix_hist<false>"}
                 traffic = pmc[pmc_name.get(KERNEL[dom], KERNEL[dom])]["hbm_bytes_per_call"]
             except (OSError, ValueError, KeyError):
                 traffic = None

@@ -1240,7 +1240,6 @@ __global__ __launch_bounds__(RT_THREADS, 3) void k2_ssort(const u64 *slA, const 
         // finished in this round whatever its length (k2 := slot, or its complement).
         u64 ev[16];
         u64 hm[16];
-        u64 dm[16];
         u32 fl[16]; // per element: GF_* bits it contributes to its group
         int lastHead = NOHEAD;
         const u32 hcur = huse[b];
@@ -1303,7 +1302,6 @@ __global__ __launch_bounds__(RT_THREADS, 3) void k2_ssort(const u64 *slA, const 
             fl[k] = f;
             u64 a = __ballot(head);
             hm[k] = a;
-            dm[k] = __ballot(f != 0);
             if (a) lastHead = rb + 63 - __clzll((unsigned long long)a);
         }
         for (int q = threadIdx.x; q < RTILE / 4; q += RT_THREADS) ((u32 *)gflag)[q] = 0;
@@ -1320,13 +1318,13 @@ __global__ __launch_bounds__(RT_THREADS, 3) void k2_ssort(const u64 *slA, const 
             u64 mo = hm[k] & le;
             ohi[k] = mo ? rb + 63 - __clzll((unsigned long long)mo) : cO;
             if (hm[k]) cO = rb + 63 - __clzll((unsigned long long)hm[k]);
-            if ((dm[k] >> lane) & 1ull)
+            if (fl[k])
                 atomicOr((u32 *)gflag + (ohi[k] >> 2), fl[k] << ((ohi[k] & 3) * 8));
         }
         __syncthreads();
         // counts
         u32 cN = 0, cU = 0;
-        u64 nmask[16], umask[16];
+        u32 st2 = 0; // per lane, 2 bits per row: bit 0 = goes to the sort, bit 1 = passes through
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const int q = w * 1024 + k * 64 + lane;
@@ -1341,10 +1339,10 @@ __global__ __launch_bounds__(RT_THREADS, 3) void k2_ssort(const u64 *slA, const 
                 const u32 code = (gf & GF_ASC) ? slot : (0xFFFFFu - slot);
                 ev[k] = (ev[k] & ~(0xFFFFFull << KEY_SHIFT)) | ((u64)code << KEY_SHIFT);
             }
-            nmask[k] = __ballot(nonuni);
-            umask[k] = __ballot(in_span && !nonuni);
-            cN += __popcll(nmask[k]);
-            cU += __popcll(umask[k]);
+            const bool uni = in_span && !nonuni;
+            st2 |= ((nonuni ? 1u : 0u) | (uni ? 2u : 0u)) << (2 * k);
+            cN += __popcll(__ballot(nonuni));
+            cU += __popcll(__ballot(uni));
         }
         if (lane == 0) {
             sm[4 + w] = (int)cN;
@@ -1363,11 +1361,13 @@ __global__ __launch_bounds__(RT_THREADS, 3) void k2_ssort(const u64 *slA, const 
         const u64 lt = (1ull << lane) - 1ull;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            if ((nmask[k] >> lane) & 1ull) buf[SZ((int)(nRun + __popcll(nmask[k] & lt)))] = ev[k];
-            if ((umask[k] >> lane) & 1ull)
-                __builtin_nontemporal_store(ev[k] & ~(0xFFFFFull << KEY_SHIFT), &out[uRun + __popcll(umask[k] & lt)]);
-            nRun += __popcll(nmask[k]);
-            uRun += __popcll(umask[k]);
+            const bool isn = (st2 >> (2 * k)) & 1u, isu = (st2 >> (2 * k + 1)) & 1u;
+            const u64 nmask = __ballot(isn), umask = __ballot(isu);
+            if (isn) buf[SZ((int)(nRun + __popcll(nmask & lt)))] = ev[k];
+            if (isu)
+                __builtin_nontemporal_store(ev[k] & ~(0xFFFFFull << KEY_SHIFT), &out[uRun + __popcll(umask & lt)]);
+            nRun += __popcll(nmask);
+            uRun += __popcll(umask);
         }
         cnt = totN;
         if (cnt == 0) return;
