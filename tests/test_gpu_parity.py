@@ -323,3 +323,27 @@ def test_long_repeat_rules(ctx, orc, seed):
             want, _ = orc.compress(d, level)
             got = ctx.compress(d, level)
             assert got == want, (name, level, d.size)
+
+
+def test_capacity_and_state_errors(ctx):
+    """Error behaviour of the C ABI: an output buffer that cannot hold the stream is refused before
+    a bit is written (BZ2HIP_E_CAP), and writing after finish is BZ2HIP_E_STATE (the reference's
+    "Write beyond end of stream", S/BZip2OutputStream.swift:69-71)."""
+    import ctypes as C
+    import bzip2_amd
+    from bzip2_amd._lib import _p
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 256, 300000, dtype=np.uint8)  # incompressible: output > input
+    out = np.zeros(200000, dtype=np.uint8)
+    n = C.c_size_t(0)
+    rc = ctx.L.bz2hip_compress(ctx.h, _p(a), a.size, 9, _p(out), out.size, C.byref(n))
+    assert rc == -4
+    assert b"too small" in ctx.L.bz2hip_last_error(ctx.h)
+    # the context stays usable
+    assert bz2.decompress(ctx.compress(a, 9)) == a.tobytes()
+    ctx.stream_begin(5)
+    ctx.stream_write(b"hello")
+    ctx.stream_finish()
+    with pytest.raises(bzip2_amd.BZ2HipError) as e:
+        ctx.stream_write(b"more")
+    assert e.value.code == -5
