@@ -120,6 +120,75 @@ __global__ __launch_bounds__(256) void k3_mtf_chunks(const u8 *__restrict__ bwt,
     }
 }
 
+// Replay by timestamps instead of by list: every symbol keeps the time it was last moved to the
+// front (4 symbols per lane: symbol v lives in lane v / 4, register v % 4); the MTF position of
+// s is the number of symbols with a later time, i.e. 4 compares + 4 scalar popcounts, and the
+// update is one register of one lane.  No list shifting: ~10 instructions per run head instead
+// of ~25.  The entry state (a list) becomes times 255 - position.
+__global__ __launch_bounds__(256) void k3_mtf_replay(const u8 *__restrict__ bwt,
+                                                     const u32 *__restrict__ nArr,
+                                                     const u32 *__restrict__ present,
+                                                     const u8 *__restrict__ mtfrec,
+                                                     u8 *__restrict__ mtfpos, u32 S, u32 CPB) {
+    const u32 b = blockIdx.y;
+    const u32 n = nArr[b];
+    __shared__ u8 smap[256];
+    __shared__ u32 ts[MTF_WG_CHUNKS][256];
+    build_symbol_map(present + b * 8, smap);
+    __syncthreads();
+    const int w = wave_id(), lane = lane_id();
+    const u32 c = blockIdx.x * MTF_WG_CHUNKS + w;
+    const u32 cbase = c * MTF_CHUNK;
+    if (cbase >= n) return;
+    const u8 *src = bwt + (size_t)b * S;
+    const u32 cend = min(cbase + MTF_CHUNK, n);
+    u8 rowv[MTF_CHUNK / 64];
+#pragma unroll
+    for (int r = 0; r < MTF_CHUNK / 64; r++) rowv[r] = src[cbase + r * 64 + lane];
+    // entry list -> times
+    {
+        const u32 st = ((const u32 *)(mtfrec + ((size_t)b * CPB + c) * 256))[lane];
+#pragma unroll
+        for (int k = 0; k < 4; k++) ts[w][(st >> (8 * k)) & 255u] = 255u - (u32)(lane * 4 + k);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+    u32 L0 = ts[w][lane * 4 + 0], L1 = ts[w][lane * 4 + 1], L2 = ts[w][lane * 4 + 2], L3 = ts[w][lane * 4 + 3];
+    u32 prev = 0xffffffffu;
+    u32 now = 256;
+#pragma unroll
+    for (int r = 0; r < MTF_CHUNK / 64; r++) {
+        const u32 rowbase = cbase + r * 64;
+        if (rowbase >= cend) break;
+        const u32 j = rowbase + lane;
+        const u32 sym = (j < cend) ? smap[rowv[r]] : 0;
+        u32 mypos = 0;
+        const u32 left = (u32)__builtin_amdgcn_update_dpp((int)prev, (int)sym, 0x138, 0xf, 0xf, false);
+        u64 heads = __ballot(j < cend && sym != left);
+        while (heads) {
+            const int i = __ffsll((unsigned long long)heads) - 1;
+            heads &= heads - 1;
+            const u32 s = __builtin_amdgcn_readlane(sym, i);
+            const int owner = (int)(s >> 2);
+            u32 t;
+            switch (s & 3u) { // wave-uniform
+            case 0: t = __builtin_amdgcn_readlane(L0, owner); if (lane == owner) L0 = now; break;
+            case 1: t = __builtin_amdgcn_readlane(L1, owner); if (lane == owner) L1 = now; break;
+            case 2: t = __builtin_amdgcn_readlane(L2, owner); if (lane == owner) L2 = now; break;
+            default: t = __builtin_amdgcn_readlane(L3, owner); if (lane == owner) L3 = now; break;
+            }
+            // symbols moved to the front after s was (s itself now holds `now`, which also counts:
+            // subtract it) -- all times are distinct
+            const u32 pos = (u32)__popcll(__ballot(L0 > t)) + (u32)__popcll(__ballot(L1 > t)) +
+                            (u32)__popcll(__ballot(L2 > t)) + (u32)__popcll(__ballot(L3 > t)) - 1u;
+            now++;
+            if (lane == i) mypos = pos;
+        }
+        prev = __builtin_amdgcn_readlane(sym, 63);
+        if (j < cend) mtfpos[(size_t)b * S + j] = (u8)mypos;
+    }
+}
+
 // Recency list of a chunk without running the MTF: last occurrence of every symbol (LDS
 // atomic max), then rank the present symbols by last occurrence, latest first.
 __global__ __launch_bounds__(256) void k3_mtf_recency(const u8 *__restrict__ bwt,
@@ -494,8 +563,7 @@ void run_mtf(bz2hip_ctx *c, int nb, u32 maxn) {
     }
     {
         ProfScope ps(c, P_MTF_REPLAY, 2.0 * (double)maxn * nb); // read bwt 1 + write pos 1 (upper bound: slots)
-        k3_mtf_chunks<true><<<gridc, 256, 0, c->stream>>>(B.bwt, B.n, B.present, B.mtfrec, B.mtfcnt,
-                                                           B.mtfpos, B.S, CPB);
+        k3_mtf_replay<<<gridc, 256, 0, c->stream>>>(B.bwt, B.n, B.present, B.mtfrec, B.mtfpos, B.S, CPB);
         KCHECK();
     }
     {
