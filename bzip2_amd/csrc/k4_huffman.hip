@@ -511,10 +511,20 @@ __global__ __launch_bounds__(256) void k7_pack_p1(const u16 *__restrict__ mtf,
     const u16 *src = mtf + (size_t)b * S2;
     const u8 *sp = sel + (size_t)b * SEL_STRIDE;
     u32 bits = 0;
+    // clamped loads first (all in flight), then the LDS lookups
+    u16 sv[PK_TILE / 256];
+    u8 tv[PK_TILE / 256];
+#pragma unroll
+    for (int k = 0; k < PK_TILE / 256; k++) {
+        const u32 j = base + k * 256 + threadIdx.x;
+        const u32 jc = j < L ? j : L - 1;
+        sv[k] = src[jc];
+        tv[k] = sp[jc / GROUP];
+    }
 #pragma unroll
     for (int k = 0; k < PK_TILE / 256; k++) {
         u32 j = base + k * 256 + threadIdx.x;
-        if (j < L) bits += ll[sp[j / GROUP] * HL + src[j]];
+        if (j < L) bits += ll[tv[k] * HL + sv[k]];
     }
     u32 tot = block_reduce_add<256>(bits, red);
     if (threadIdx.x == 0) pkagg[(size_t)b * PKT + blockIdx.x] = tot;
@@ -559,11 +569,20 @@ __global__ __launch_bounds__(256) void k7_pack_p3(
     const u8 *sp = sel + (size_t)b * SEL_STRIDE;
     u32 mc[PK_PER_THREAD];
     u32 bits = 0;
+    u16 sv[PK_PER_THREAD];
+    u8 tv[PK_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < PK_PER_THREAD; k++) {
+        const u32 j = base + threadIdx.x * PK_PER_THREAD + k;
+        const u32 jc = j < L ? j : L - 1;
+        sv[k] = src[jc];
+        tv[k] = sp[jc / GROUP];
+    }
 #pragma unroll
     for (int k = 0; k < PK_PER_THREAD; k++) {
         u32 j = base + threadIdx.x * PK_PER_THREAD + k;
         u32 m = 0;
-        if (j < L) m = codes[sp[j / GROUP] * HL + src[j]];
+        if (j < L) m = codes[tv[k] * HL + sv[k]];
         mc[k] = m;
         bits += m >> 24;
     }
