@@ -338,8 +338,16 @@ static size_t compress_core(bz2hip_ctx *c, const u8 *d_in, size_t n, int level, 
             run_bwt_n(c, nb, bs);
             run_mtf(c, nb, bs);
             run_huffman(c, nb, bs + 1);
-            if (pend.valid) finish(pend);
-            pend = {true, lane, nb, final && trailer && last_window && (b0 + nb == usable)};
+            const Pending cur = {true, lane, nb, final && trailer && last_window && (b0 + nb == usable)};
+            if (two) {
+                // the previous batch lives in the other lane: pack it now, keep this one pending
+                if (pend.valid) finish(pend);
+                pend = cur;
+            } else {
+                // one lane only (the block estimate can be short of the real count, so several
+                // batches may still be needed): pack before the workspace is reused
+                finish(cur);
+            }
         }
         if (pend.valid) finish(pend);
         if (c->active_lane != lane0) c->swap_lane();

@@ -347,3 +347,17 @@ def test_capacity_and_state_errors(ctx):
     with pytest.raises(bzip2_amd.BZ2HipError) as e:
         ctx.stream_write(b"more")
     assert e.value.code == -5
+
+
+def test_more_blocks_than_estimated(ctx, orc):
+    """Blocks full of 4-byte runs take fewer than bs - 4 input bytes each, so a window holds more
+    blocks than length / (bs - 4): the batches must still come out in order (regression: a
+    single-lane context reused its workspace before the previous batch was packed)."""
+    rng = np.random.default_rng(11)
+    vals = rng.integers(0, 256, 200000, dtype=np.uint8)
+    d = np.repeat(vals, 4)[:790000]          # runs of exactly 4: RLE1 expands 4 -> 5
+    for level in (1, 2):
+        want, nb = orc.compress(d, level)
+        assert nb > d.size // (level * 100000 - 4) + 1
+        got = ctx.compress(d, level)
+        assert got == want, level
