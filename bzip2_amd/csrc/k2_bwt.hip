@@ -462,8 +462,21 @@ __device__ __forceinline__ void tile_emit(const u64 *buf, int cnt, const int (&c
                                           u32 *__restrict__ rank, const u8 *__restrict__ T,
                                           u8 *__restrict__ bwt, u32 n, u64 *__restrict__ sOut,
                                           u32 *mSn_b, u64 *__restrict__ lOut, u32 lBase,
-                                          int *sm /* 12 ints */) {
+                                          int *sm /* 12 ints */, u32 rlo = 0, u32 rhi = ~0u,
+                                          bool mainSweep = true) {
     const int w = wave_id(), lane = lane_id();
+    if (!mainSweep) {
+        // a later sweep of round 0: only the ranks of positions in [rlo, rhi)
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int idx = w * 1024 + k * 64 + lane;
+            if (cls[k] != CLS_NONE) {
+                const u32 i = (u32)(BUFX(idx) & E_IMASK);
+                if (i >= rlo && i < rhi) rank[i] = ngrp[k];
+            }
+        }
+        return;
+    }
     // counts of SMALL and LKEEP per wave
     u32 cs = 0, cl = 0;
 #pragma unroll
@@ -518,7 +531,7 @@ __device__ __forceinline__ void tile_emit(const u64 *buf, int cnt, const int (&c
             const u64 e_ = BUFX(idx);
             i = (u32)(e_ & E_IMASK);
             // the first sub-group of a split group keeps its rank: no write
-            if (MODE == MODE_ROUND0 || (MODE == MODE_NORMAL && ngrp[k] != (u32)(e_ >> 40))) rank[i] = ngrp[k];
+            if (MODE == MODE_ROUND0 ? (i >= rlo && i < rhi) : (MODE == MODE_NORMAL && ngrp[k] != (u32)(e_ >> 40))) rank[i] = ngrp[k];
             if (MODE == MODE_FINAL || c == CLS_SINGLE) bwt[spos[k]] = tb[k];
         }
         if (MODE != MODE_FINAL) {
@@ -644,11 +657,17 @@ __global__ __launch_bounds__(RT_THREADS) void k2_lrerank_p3(
     const u32 *__restrict__ par, const u32 *__restrict__ cntArr,
     const u32 *__restrict__ state, u32 want, const u32 *__restrict__ tileagg,
     u32 *__restrict__ rank, const u8 *__restrict__ T, u8 *__restrict__ bwt,
-    const u32 *__restrict__ nArr, u32 *__restrict__ mSn, u32 S, u32 TPB, u32 gtiles, u32 gnb) {
-    XCD_MAP(gtiles, gnb)
+    const u32 *__restrict__ nArr, u32 *__restrict__ mSn, u32 S, u32 TPB, u32 gtiles, u32 gnb,
+    u32 nsw) {
+    // round 0 writes the rank of every position, in sorted order: a block's rank array does not
+    // stay in its XCD's L2 next to the streaming lists, so the pass is swept nsw times, each
+    // sweep writing only the ranks that fall in one 1/nsw window of positions
+    XCD_MAP(gtiles * nsw, gnb)
     const u32 b = bz_b;
     if (state[b] != want) return;
     const u32 m = cntArr[b];
+    const u32 sweep = bz_t / gtiles;
+    bz_t -= sweep * gtiles;
     const u32 base = bz_t * RTILE;
     if (base >= m) return;
     __shared__ u64 buf[RTILE];
@@ -681,8 +700,10 @@ __global__ __launch_bounds__(RT_THREADS) void k2_lrerank_p3(
     tile_classify<MODE>(buf, cnt, prevE, has_prev, carryOld, carryNew, end_head, sm, cls, ngrp, spos, nheads);
     // S survivors go to the buffer the S-kernel of this round also appends to
     u64 *sOut = (par[b] ? slA : slB) + (size_t)b * S;
+    const u32 nblk = nArr[b], win = (nblk + nsw - 1) / nsw;
     tile_emit<MODE>(buf, cnt, cls, ngrp, spos, rank + (size_t)b * S, T + (size_t)b * S,
-                    bwt + (size_t)b * S, nArr[b], sOut, mSn + b, lOutAll + (size_t)b * S, lBase, sm);
+                    bwt + (size_t)b * S, nblk, sOut, mSn + b, lOutAll + (size_t)b * S, lBase, sm,
+                    nsw > 1 ? sweep * win : 0u, nsw > 1 ? (sweep + 1) * win : ~0u, sweep == 0);
 }
 
 // ------------------------------------------------------------------ S-path: sort in LDS
@@ -1506,9 +1527,15 @@ static void lrerank(bz2hip_ctx *c, int nb, u32 maxcnt, const u32 *cntArr, u32 wa
     k2_lrerank_p2<<<nb, 256, 0, c->stream>>>(cntArr, B.state, want, B.tileagg, B.mLn, B.leftg,
                                              MODE == MODE_FINAL ? 1 : 0, B.TPB);
     KCHECK();
-    k2_lrerank_p3<MODE><<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(sorted, lout, B.slA, B.slB, B.par, cntArr,
-                                                            B.state, want, B.tileagg, B.rank, B.T,
-                                                            B.bwt, B.n, B.mSn, B.S, B.TPB, tiles, nbarg(nb, 4));
+    static const u32 r0_sweeps = [] {
+        const char *e = getenv("BZ2HIP_RSWEEPS");
+        int v = e ? atoi(e) : 2;
+        return (u32)(v < 1 ? 1 : v > 16 ? 16 : v);
+    }();
+    const u32 nsw = (MODE == MODE_ROUND0) ? r0_sweeps : 1u;
+    k2_lrerank_p3<MODE><<<xcd_grid(tiles * nsw, nb), RT_THREADS, 0, c->stream>>>(
+        sorted, lout, B.slA, B.slB, B.par, cntArr, B.state, want, B.tileagg, B.rank, B.T, B.bwt, B.n,
+        B.mSn, B.S, B.TPB, tiles, nbarg(nb, 4), nsw);
     KCHECK();
 }
 

@@ -154,6 +154,12 @@ __global__ __launch_bounds__(256) void k3_mtf_replay(const u8 *__restrict__ bwt,
         __builtin_amdgcn_wave_barrier();
     }
     u32 L0 = ts[w][lane * 4 + 0], L1 = ts[w][lane * 4 + 1], L2 = ts[w][lane * 4 + 2], L3 = ts[w][lane * 4 + 3];
+    // ts[w][] stays a mirror of the registers: the time of the head's symbol is read from it (one
+    // uniform LDS read, issued one head ahead: consecutive heads are different symbols), so no
+    // register has to be selected by s & 3; the update compares all four ids of the lane with s
+    const u32 id0 = (u32)lane * 4u;
+    typedef __attribute__((address_space(3))) u32 lds_u32;
+    lds_u32 *const tsw = (lds_u32 *)&ts[w][0];
     u32 prev = 0xffffffffu;
     u32 now = 256;
 #pragma unroll
@@ -165,24 +171,39 @@ __global__ __launch_bounds__(256) void k3_mtf_replay(const u8 *__restrict__ bwt,
         u32 mypos = 0;
         const u32 left = (u32)__builtin_amdgcn_update_dpp((int)prev, (int)sym, 0x138, 0xf, 0xf, false);
         u64 heads = __ballot(j < cend && sym != left);
-        while (heads) {
-            const int i = __ffsll((unsigned long long)heads) - 1;
-            heads &= heads - 1;
-            const u32 s = __builtin_amdgcn_readlane(sym, i);
-            const int owner = (int)(s >> 2);
-            u32 t;
-            switch (s & 3u) { // wave-uniform
-            case 0: t = __builtin_amdgcn_readlane(L0, owner); if (lane == owner) L0 = now; break;
-            case 1: t = __builtin_amdgcn_readlane(L1, owner); if (lane == owner) L1 = now; break;
-            case 2: t = __builtin_amdgcn_readlane(L2, owner); if (lane == owner) L2 = now; break;
-            default: t = __builtin_amdgcn_readlane(L3, owner); if (lane == owner) L3 = now; break;
+        if (heads) {
+            // one head: (iA, pA = &ts[w][sA], tA) is the head being placed; the next head's index,
+            // mirror slot and time are fetched first.  Two copies with the roles swapped, so that
+            // nothing has to be moved between iterations.
+#define MTF_HEAD(iA, sA, pA, tA, iB, sB, pB, tB)                                                       \
+    iA = __builtin_ctzll((unsigned long long)heads);                                                   \
+    asm("s_bitset0_b64 %0, %1" : "+s"(heads) : "s"(iA));                                               \
+    iB = __builtin_ctzll((unsigned long long)heads) & 63;                                              \
+    sB = __builtin_amdgcn_readlane(sym, iB); /* lane 63 when no head is left: harmless */              \
+    pB = tsw + sB;                                                                                     \
+    tB = *pB;                                                                                          \
+    {                                                                                                  \
+        const u32 pos = (u32)__popcll(__ballot(L0 > tA)) + (u32)__popcll(__ballot(L1 > tA)) +          \
+                        (u32)__popcll(__ballot(L2 > tA)) + (u32)__popcll(__ballot(L3 > tA));           \
+        L0 = (id0 == sA) ? now : L0;                                                                   \
+        L1 = (id0 + 1u == sA) ? now : L1;                                                              \
+        L2 = (id0 + 2u == sA) ? now : L2;                                                              \
+        L3 = (id0 + 3u == sA) ? now : L3;                                                              \
+        *pA = now; /* every lane, same slot, same value: cheaper than narrowing exec */               \
+        if (lane == iA) mypos = pos;                                                                   \
+        now++;                                                                                         \
+    }
+            int iA = __builtin_ctzll((unsigned long long)heads), iB;
+            u32 sA = __builtin_amdgcn_readlane(sym, iA), sB;
+            lds_u32 *pA = tsw + sA, *pB;
+            u32 tA = *pA, tB;
+            while (true) {
+                MTF_HEAD(iA, sA, pA, tA, iB, sB, pB, tB)
+                if (!heads) break;
+                MTF_HEAD(iB, sB, pB, tB, iA, sA, pA, tA)
+                if (!heads) break;
             }
-            // symbols moved to the front after s was (s itself now holds `now`, which also counts:
-            // subtract it) -- all times are distinct
-            const u32 pos = (u32)__popcll(__ballot(L0 > t)) + (u32)__popcll(__ballot(L1 > t)) +
-                            (u32)__popcll(__ballot(L2 > t)) + (u32)__popcll(__ballot(L3 > t)) - 1u;
-            now++;
-            if (lane == i) mypos = pos;
+#undef MTF_HEAD
         }
         prev = __builtin_amdgcn_readlane(sym, 63);
         if (j < cend) mtfpos[(size_t)b * S + j] = (u8)mypos;
