@@ -136,7 +136,7 @@ def main():
             # dominant kernel class = the one with the most GPU time among those with a defined
             # algorithmic byte count
             KERNEL = {"radix_scatter": "k2_radix_scatter", "radix_hist": "k2_radix_hist",
-                      "bwt_keys": "k2_keys", "bwt_ssort": "k2_ssort", "mtf_replay": "k3_mtf_chunks<true>"}
+                      "bwt_keys": "k2_keys", "bwt_ssort": "k2_ssort", "mtf_replay": "k3_mtf_replay"}
             dom = max(KERNEL, key=lambda k: prof[k]["ms"])
             sc = prof[dom]
             launches = max(sc["launches"], 1)
@@ -149,7 +149,7 @@ def main():
             try:
                 with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
                     pmc = json.load(f)
-                pmc_name = {"k2_ssort": "void k2_ssort<0>", "k3_mtf_chunks<true>": "void k3_mtf_chunks<true>",
+                pmc_name = {"k2_ssort": "void k2_ssort<0>",
                             "k2_radix_scatter": "void k2_radix_scatter<false>",
                             "k2_radix_hist": "void k2_radix_hist<false>"}
                 traffic = pmc[pmc_name.get(KERNEL[dom], KERNEL[dom])]["hbm_bytes_per_call"]
@@ -188,13 +188,16 @@ def main():
             tc = time.perf_counter()
             o2, _ = orc.compress(sample, args.level, threads=cores)
             tm = time.perf_counter() - tc
+            # the same sample through the GPU path must give the oracle's bytes (checker, not timed)
+            ln = ctx.compress_device(d_in.data_ptr(), int(sample.size), args.level, d_out.data_ptr(), cap)
+            same = d_out[:ln].cpu().numpy().tobytes() == bytes(o1) and bytes(o1) == bytes(o2)
             res["cpu_baseline"] = {"value": round(sample.size / t1 / 1e6, 2), "unit": "MB/s",
                                    "cores": 1, "kind": "port",
                                    "sample": f"first {sample.size >> 20} MiB of the same corpus, "
                                              f"C oracle -O2, 1 thread",
                                    "all_cores": {"value": round(sample.size / tm / 1e6, 2),
                                                  "cores": cores},
-                                   "gpu_prefix_matches": None}
+                                   "gpu_output_equals_oracle": same}
         print(json.dumps(res), flush=True)
     ctx.close()
     if world > 1:
