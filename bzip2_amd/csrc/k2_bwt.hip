@@ -1172,6 +1172,25 @@ __global__ __launch_bounds__(RT_THREADS) void k2_lap_p3(u64 *__restrict__ keyA,
     }
 }
 
+#ifdef EXP_TIMING
+__device__ unsigned long long g_phase[8];
+__device__ unsigned long long g_hist[4];
+extern "C" void bz2hip_debug_phases(unsigned long long *out) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 8);
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z));
+}
+extern "C" void bz2hip_debug_hist(unsigned long long *out) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hist), sizeof(unsigned long long) * 4);
+    unsigned long long z[4] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_hist), z, sizeof(z));
+}
+#define PH_MARK(k) do { __syncthreads(); if (threadIdx.x == 0) { unsigned long long t_ = wall_clock64(); atomicAdd(&g_phase[k], t_ - ph_t); ph_t = t_; } } while (0)
+#define PH_INIT unsigned long long ph_t = wall_clock64();
+#else
+#define PH_MARK(k)
+#define PH_INIT
+#endif
 template <int MODE>
 __global__ __launch_bounds__(RT_THREADS, 3) void k2_ssort(const u64 *slA, const u64 *slB,
                                                        u64 *slAo, u64 *slBo,
@@ -1192,6 +1211,7 @@ __global__ __launch_bounds__(RT_THREADS, 3) void k2_ssort(const u64 *slA, const 
     const u32 m = mS[b];
     const u32 t0 = bz_t * SC;
     if (t0 >= m) return;
+    PH_INIT
     __shared__ u64 buf[RTILE];
     __shared__ int sm[16];
     __shared__ int s_start, s_end;
@@ -1247,6 +1267,7 @@ __global__ __launch_bounds__(RT_THREADS, 3) void k2_ssort(const u64 *slA, const 
     const int start = s_start, end = s_end;
     if (start == CROSS) return; // owns nothing
     int cnt = end - start;
+    PH_MARK(0);
     const int w = wave_id(), lane = lane_id();
     if (MODE == MODE_NORMAL) {
         // Groups whose k2 is the same for every member cannot split this round: they pass
@@ -1327,6 +1348,7 @@ __global__ __launch_bounds__(RT_THREADS, 3) void k2_ssort(const u64 *slA, const 
         }
         for (int q = threadIdx.x; q < RTILE / 4; q += RT_THREADS) ((u32 *)gflag)[q] = 0;
         if (lane == 0) sm[w] = lastHead;
+        PH_MARK(5);
         __syncthreads();
         int cO = NOHEAD;
         for (int q = 0; q < w; q++)
@@ -1342,6 +1364,7 @@ __global__ __launch_bounds__(RT_THREADS, 3) void k2_ssort(const u64 *slA, const 
             if (fl[k])
                 atomicOr((u32 *)gflag + (ohi[k] >> 2), fl[k] << ((ohi[k] & 3) * 8));
         }
+        PH_MARK(6);
         __syncthreads();
         // counts
         u32 cN = 0, cU = 0;
@@ -1370,6 +1393,7 @@ __global__ __launch_bounds__(RT_THREADS, 3) void k2_ssort(const u64 *slA, const 
             sm[8 + w] = (int)cU;
         }
         __syncthreads();
+        PH_MARK(7);
         const int totN = sm[4] + sm[5] + sm[6] + sm[7];
         const int totU = sm[8] + sm[9] + sm[10] + sm[11];
         if (threadIdx.x == 0) sm[12] = totU ? (int)atomicAdd(mSn + b, (u32)totU) : 0;
@@ -1392,12 +1416,33 @@ __global__ __launch_bounds__(RT_THREADS, 3) void k2_ssort(const u64 *slA, const 
         }
         cnt = totN;
         if (cnt == 0) return;
+#ifdef EXP_TIMING
+        {
+            // experiment: largest sorted group of the window, weighted by the sorted count
+            int mx = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                if ((st2 >> (2 * k)) & 1u) mx = max(mx, w * 1024 + k * 64 + lane - ohi[k] + 1);
+            __shared__ int s_mx;
+            if (threadIdx.x == 0) s_mx = 0;
+            __syncthreads();
+            atomicMax(&s_mx, mx);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int m_ = s_mx;
+                const int slot = m_ <= 8 ? 0 : m_ <= 32 ? 1 : m_ <= 128 ? 2 : 3;
+                atomicAdd(&g_hist[slot], (unsigned long long)cnt);
+            }
+        }
+#endif
         int N = 64;
         while (N < cnt) N <<= 1;
         __syncthreads();
         for (int q = cnt + threadIdx.x; q < N; q += RT_THREADS) buf[SZ(q)] = ~0ull;
         __syncthreads();
+        PH_MARK(1);
         bitonic_sort_lds(buf, N);
+        PH_MARK(2);
     } else {
         // FINAL: order inside groups is irrelevant; keep the span in place at buf[0..cnt)
         int N = 256;
@@ -1412,8 +1457,10 @@ __global__ __launch_bounds__(RT_THREADS, 3) void k2_ssort(const u64 *slA, const 
     int nheads;
     tile_classify<MODE, true>(buf, cnt, 0, false, NOHEAD, NOHEAD, true, sm, cls, ngrp, spos, nheads);
     if (MODE == MODE_FINAL && threadIdx.x == 0) atomicAdd(&leftg[b], (u32)nheads);
+    PH_MARK(3);
     tile_emit<MODE, true>(buf, cnt, cls, ngrp, spos, rank + (size_t)b * S, T + (size_t)b * S,
                     bwt + (size_t)b * S, nArr[b], out, mSn + b, (u64 *)nullptr, 0, sm);
+    PH_MARK(4);
 }
 
 // ------------------------------------------------------------------ finish
