@@ -111,4 +111,12 @@ void orc_set_tie_rule(int rule);
 #ifdef __cplusplus
 }
 #endif
+/* ---- decoder restatement (bz2_decode_oracle.c).  Return 0 or a negative ORC_D_* code. */
+int orc_decompress(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *produced,
+                   int *n_blocks);
+int orc_decode_block(const uint8_t *in, size_t n, uint64_t bitpos, int block_size, uint8_t *bwt,
+                     int *n_bwt, uint32_t *orig, uint32_t *crc, uint64_t *end_bit);
+int orc_inverse_bwt(const uint8_t *bwt, int n, uint32_t orig, uint8_t *tt);
+int orc_unrle1(const uint8_t *tt, int n, uint8_t *out, size_t cap, size_t *out_len, uint32_t *crc);
+
 #endif

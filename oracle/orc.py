@@ -20,7 +20,7 @@ def build(force=False):
     if force or not os.path.exists(_SO) or (
         os.path.exists(os.path.join(_HERE, "bz2_oracle.c"))
         and os.path.getmtime(_SO) < max(os.path.getmtime(os.path.join(_HERE, f))
-                                        for f in ("bz2_oracle.c", "divsufsort_restate.c", "bz2_oracle.h"))
+                                        for f in ("bz2_oracle.c", "divsufsort_restate.c", "bz2_decode_oracle.c", "bz2_oracle.h"))
     ):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
@@ -80,6 +80,18 @@ def lib():
         L.orc_divsufsort_traps.argtypes = []
         L.orc_set_tie_rule.restype = None
         L.orc_set_tie_rule.argtypes = [C.c_int]
+        L.orc_decompress.restype = C.c_int
+        L.orc_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                     C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
+        L.orc_decode_block.restype = C.c_int
+        L.orc_decode_block.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64, C.c_int, C.c_void_p,
+                                       C.POINTER(C.c_int), C.POINTER(C.c_uint32),
+                                       C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+        L.orc_inverse_bwt.restype = C.c_int
+        L.orc_inverse_bwt.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p]
+        L.orc_unrle1.restype = C.c_int
+        L.orc_unrle1.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
+                                 C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]
         _lib = L
     return _lib
 
@@ -234,3 +246,44 @@ def divsufsort_traps():
 
 def set_tie_rule(rule):
     lib().orc_set_tie_rule(rule)
+
+
+# ---- decoder restatement (bz2_decode_oracle.c)
+D_OK, D_INSUFFICIENT, D_HEADER, D_FORMAT, D_BLOCK_CRC, D_STREAM_CRC = 0, -1, -2, -3, -4, -5
+D_TABLES, D_BLOCK_SIZE, D_START_PTR, D_DECODE, D_RANDOMISED, D_CAPACITY = -6, -7, -8, -9, -10, -11
+
+
+def decompress(stream, cap):
+    """-> (rc, bytes the reference would have handed out before failing, blocks)"""
+    a = _u8(stream)
+    out = np.zeros(max(cap, 1), dtype=np.uint8)
+    produced = C.c_size_t(0)
+    nb = C.c_int(0)
+    rc = lib().orc_decompress(_ptr(a), a.size, _ptr(out), cap, C.byref(produced), C.byref(nb))
+    return rc, out[:produced.value].tobytes(), nb.value
+
+
+def decode_block(stream, bitpos, block_size):
+    """block whose magic starts at bit `bitpos` -> (rc, bwt bytes, orig, crc, end bit)"""
+    a = _u8(stream)
+    bwt_ = np.zeros(block_size, dtype=np.uint8)
+    n = C.c_int(0)
+    orig, crc, end = C.c_uint32(0), C.c_uint32(0), C.c_uint64(0)
+    rc = lib().orc_decode_block(_ptr(a), a.size, bitpos, block_size, _ptr(bwt_), C.byref(n),
+                                C.byref(orig), C.byref(crc), C.byref(end))
+    return rc, bwt_[:n.value].copy(), orig.value, crc.value, end.value
+
+
+def inverse_bwt(bwt_bytes, orig):
+    a = _u8(bwt_bytes)
+    tt = np.zeros(max(a.size, 1), dtype=np.uint8)
+    rc = lib().orc_inverse_bwt(_ptr(a), a.size, orig, _ptr(tt))
+    return rc, tt[:a.size]
+
+
+def unrle1(tt, cap):
+    a = _u8(tt)
+    out = np.zeros(max(cap, 1), dtype=np.uint8)
+    ol, crc = C.c_size_t(0), C.c_uint32(0)
+    rc = lib().orc_unrle1(_ptr(a), a.size, _ptr(out), cap, C.byref(ol), C.byref(crc))
+    return rc, out[:ol.value], crc.value
