@@ -22,7 +22,7 @@ SYMBOLS = [
     "bz2hip_stream_begin", "bz2hip_stream_write", "bz2hip_stream_finish", "bz2hip_stream_read",
     "bz2hip_stream_pending", "bz2hip_rle1_split", "bz2hip_bwt", "bz2hip_mtf_rle2",
     "bz2hip_huffman", "bz2hip_block_compress", "bz2hip_profile_reset", "bz2hip_profile_get", "bz2hip_last_stats3",
-    "bz2hip_last_stats", "bz2hip_last_stats2",
+    "bz2hip_last_stats", "bz2hip_last_stats2", "bz2hip_decompress", "bz2hip_decompress_device",
 ]
 
 
@@ -100,6 +100,10 @@ def load():
     L.bz2hip_last_stats2.argtypes = [vp, vp, vp]
     L.bz2hip_last_stats3.restype = C.c_int
     L.bz2hip_last_stats3.argtypes = [vp, vp, vp]
+    L.bz2hip_decompress.restype = C.c_int
+    L.bz2hip_decompress.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
+    L.bz2hip_decompress_device.restype = C.c_int
+    L.bz2hip_decompress_device.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
     _lib = L
     return L
 
@@ -166,6 +170,24 @@ class Context:
         n = C.c_size_t(0)
         self._chk(self.L.bz2hip_compress(self.h, _p(a), a.size, level, _p(out), cap, C.byref(n)))
         return out[: n.value].tobytes()
+
+    # ---- decoder: (rc, bytes the reference would have handed out before failing); rc 0 = whole stream
+    def decompress(self, stream, cap):
+        a = np.frombuffer(bytes(stream), dtype=np.uint8)
+        out = np.empty(max(cap, 1), dtype=np.uint8)
+        n = C.c_size_t(0)
+        rc = self.L.bz2hip_decompress(self.h, _p(a), a.size, _p(out), cap, C.byref(n))
+        if rc in (-1, -2, -3):
+            self._chk(rc)
+        return rc, out[: n.value].tobytes()
+
+    def decompress_device(self, d_in_ptr, n, d_out_ptr, cap):
+        got = C.c_size_t(0)
+        rc = self.L.bz2hip_decompress_device(self.h, C.c_void_p(d_in_ptr), n, C.c_void_p(d_out_ptr), cap,
+                                             C.byref(got))
+        if rc in (-1, -2, -3):
+            self._chk(rc)
+        return rc, got.value
 
     def compress_device(self, d_in_ptr, n, level, d_out_ptr, cap):
         got = C.c_size_t(0)

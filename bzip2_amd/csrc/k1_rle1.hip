@@ -530,6 +530,18 @@ u32 run_split(bz2hip_ctx *c, const u8 *d_in, u32 n, int level, u32 *d_rs, u32 *d
     return cnt;
 }
 
+// CRC of nb byte ranges [starts[b], starts[b+1]) of d_data (the decoder's use of the CRC kernels)
+void run_crc_blocks(bz2hip_ctx *c, const u8 *d_data, const u32 *d_starts, int nb, u32 max_len,
+                    u32 *d_cagg, u32 ETPB, u32 *d_crc) {
+    const u32 tiles = (max_len + K1_TILE - 1) / K1_TILE;
+    if (tiles) {
+        k1_crc_p1<<<dim3(tiles, nb), 256, 0, c->stream>>>(d_data, d_starts, d_cagg, ETPB);
+        KCHECK();
+    }
+    k1_crc_p2<<<(nb + 63) / 64, 64, 0, c->stream>>>(d_starts, d_cagg, d_crc, nb, ETPB);
+    KCHECK();
+}
+
 // RLE1-encode blocks [b0, b0+nb) of the window into the batch; CRC per block.
 void run_rle1_emit(bz2hip_ctx *c, const u8 *d_in, const u32 *d_rs, const u32 *d_starts, u32 b0,
                    int nb, u32 max_in_len, u32 *d_eagg, u32 ETPB) {

@@ -1,0 +1,767 @@
+// kd_decode.hip -- block-parallel bzip2 decoder.
+//
+// Replaces BZip2InputStream (S/BZip2InputStream.swift:154-242), BZip2BlockDecompressor
+// (S/BZip2BlockDecompressor.swift:199-483), BZip2HuffmanStageDecoder (S/BZip2HuffmanStageDecoder.swift:
+// 84-181) and BZip2BitInputStream (S/BZip2BitInputStream.swift:53-146) for a whole stream resident in
+// HBM.  The reference decodes one block after the other; here every block is decoded at once:
+//   kd_scan_magic : every bit offset is tested for the 48-bit block magic (blocks abut at any bit)
+//   kd_huff       : one wavefront per candidate: header, selectors, code lengths, canonical tables,
+//                   then the serial Huffman / RUNA-RUNB / inverse MTF loop (list 4 entries per lane,
+//                   DPP rotate) -> BWT bytes, origin pointer, stored CRC, end bit
+//   host          : walks the chain magic -> end bit -> magic from bit 32; anything a candidate
+//                   that is not on the chain decoded is ignored
+//   kd_hist / kd_merge : stable counting sort of the BWT bytes = the reference's merged pointers
+//   kd_walk_a/b/c : the n-step pointer walk as list ranking: every 128th node (+ the origin) is a
+//                   ruler; a) each ruler walks to the next ruler, b) one lane per block walks the
+//                   ruler chain from the origin and gives each ruler its output offset, c) each
+//                   ruler walks again and writes its bytes.  A walk that returns to the origin before
+//                   n steps (block = w^k: k cycles) is written once and replicated (kd_cycfill).
+//   kd_unrle      : final run-length decoding, a wave per block over rows of 64 bytes: which bytes
+//                   are repeat counts is a 2-state automaton over runs of equal bytes (state = "the
+//                   next byte is a count"), scanned inside the row by function composition
+//   k1_crc_p1/p2  : block CRCs of the decoded bytes (the encoder's kernels)
+// Randomised blocks (S/BZip2BlockDecompressor.swift:367-374) are not supported: BZ2HIP_E_RANDOMISED.
+#include "ctx.hpp"
+#include <algorithm>
+#include <vector>
+
+#define KD_WIN 4096    // compressed bytes staged in LDS per refill
+#define KD_RULER 128
+#define KD_MAXLEN 23   // HUFFMAN_DECODE_MAXIMUM_CODE_LENGTH, S/BZip2Constants.swift:57
+
+enum { KS_OK = 0, KS_INSUFFICIENT, KS_TABLES, KS_BLOCK_SIZE, KS_DECODE, KS_RANDOMISED };
+// meta words per candidate
+enum { KM_STATUS = 0, KM_N, KM_ORIG, KM_CRC, KM_END_LO, KM_END_HI, KM_WORDS = 8 };
+
+void run_crc_blocks(bz2hip_ctx *c, const u8 *d_data, const u32 *d_starts, int nb, u32 max_len,
+                    u32 *d_cagg, u32 ETPB, u32 *d_crc); // k1_rle1.hip
+
+// ------------------------------------------------------------------ block magic scan
+__global__ __launch_bounds__(256) void kd_scan_magic(const u8 *__restrict__ in, u64 nbytes,
+                                                     u64 *__restrict__ cand, u32 *__restrict__ ncand,
+                                                     u32 cap) {
+    const u64 p = (u64)blockIdx.x * 256u + threadIdx.x;
+    if (p >= nbytes) return;
+    u64 v = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) v = (v << 8) | (u64)((p + q < nbytes) ? in[p + q] : 0);
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        if (((v << s) >> 16) == 0x314159265359ull && p * 8u + s + 48u <= nbytes * 8u) {
+            const u32 slot = atomicAdd(ncand, 1u);
+            if (slot < cap) cand[slot] = p * 8u + s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ Huffman + MTF stage
+// inverse of mtf_step (k3_mtf.hip): the symbol at position p goes to the front
+__device__ __forceinline__ u32 kd_index_to_front(u32 &L, u32 p) {
+    const int lane = lane_id();
+    const int src = (int)(p >> 2);
+    const u32 k = p & 3u;
+    const u32 w = __builtin_amdgcn_readlane(L, src);
+    const u32 v = (w >> (8u * k)) & 255u;
+    if (p != 0) {
+        u32 up = (u32)__builtin_amdgcn_update_dpp(0, (int)L, 0x138, 0xf, 0xf, false); // wave_shr:1
+        u32 carry = (lane == 0) ? v : (up >> 24);
+        u32 shifted = (L << 8) | carry;
+        if (lane < src) {
+            L = shifted;
+        } else if (lane == src) {
+            u32 keep = (k == 3) ? 0u : (0xffffffffu << (8u * (k + 1u)));
+            L = (shifted & ~keep) | (L & keep);
+        }
+    }
+    return v;
+}
+
+struct KdBits {
+    const u8 *in;
+    u64 nbytes, pos, wbase; // pos = next byte to enter the bit buffer; window = [wbase, wbase + KD_WIN)
+    u64 bb;                 // bit buffer, MSB first
+    int bc;                 // valid bits in bb
+    u8 *win;
+    __device__ __forceinline__ void load_window(u64 at) {
+        wbase = at;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        for (int j = 0; j < KD_WIN / 64; j++) {
+            const u64 a = at + (u64)j * 64u + (u64)lane_id();
+            win[j * 64 + lane_id()] = (a < nbytes) ? in[a] : (u8)0;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ void fill() {
+        while (bc <= 56) {
+            if (pos >= wbase + KD_WIN) load_window(pos);
+            bb |= (u64)win[pos - wbase] << (56 - bc);
+            bc += 8;
+            pos++;
+        }
+    }
+    __device__ __forceinline__ u32 peek(int k) { return k ? (u32)(bb >> (64 - k)) : 0u; }
+    __device__ __forceinline__ void skip(int k) { bb = (k >= 64) ? 0ull : (bb << k); bc -= k; }
+    __device__ __forceinline__ u32 bits(int k) { fill(); u32 v = peek(k); skip(k); return v; }
+    __device__ __forceinline__ u64 consumed() const { return pos * 8u - (u64)bc; }
+    // the reference fails when it needs a byte that is not there: a consumed bit past the end
+    __device__ __forceinline__ bool over() const { return consumed() > nbytes * 8u; }
+};
+
+__global__ __launch_bounds__(64) void kd_huff(const u8 *__restrict__ in, u64 nbytes,
+                                              const u64 *__restrict__ cand, u32 block_size, u32 S,
+                                              u8 *__restrict__ bwt, u32 *__restrict__ meta) {
+    const u32 b = blockIdx.x;
+    const int lane = lane_id();
+    __shared__ u8 win[KD_WIN];
+    __shared__ u8 sel[SEL_MAX + 2];
+    __shared__ u8 lens[6][MAX_ALPHA + 2];
+    __shared__ int limits[6][KD_MAXLEN + 1];
+    __shared__ int bases[6][KD_MAXLEN + 2];
+    __shared__ u16 symbols[6][MAX_ALPHA + 2];
+    __shared__ int minlen[6];
+    __shared__ u8 symmap[256];
+    __shared__ u8 tmtf[256];
+    u32 *mt = meta + (size_t)b * KM_WORDS;
+    u8 *out = bwt + (size_t)b * S;
+
+    KdBits br;
+    br.in = in; br.nbytes = nbytes; br.win = win; br.bb = 0; br.bc = 0;
+    const u64 startbit = cand[b] + 48u;
+    br.pos = startbit >> 3;
+    br.load_window(br.pos);
+    if (startbit & 7u) (void)br.bits((int)(startbit & 7u));
+
+    u32 status = KS_OK, len = 0, orig = 0, crc = 0;
+    // zeroed tables: a selector may name a table the block does not define (the reference's arrays
+    // are zero-initialised, S/BZip2HuffmanStageDecoder.swift:44-61)
+    for (int q = lane; q < 6 * (KD_MAXLEN + 1); q += 64) (&limits[0][0])[q] = 0;
+    for (int q = lane; q < 6 * (KD_MAXLEN + 2); q += 64) (&bases[0][0])[q] = 0;
+    for (int q = lane; q < 6 * (MAX_ALPHA + 2); q += 64) { (&symbols[0][0])[q] = 0; (&lens[0][0])[q] = 0; }
+    for (int q = lane; q < 256; q += 64) { symmap[q] = 0; tmtf[q] = (u8)q; }
+    if (lane < 6) minlen[lane] = 0;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+
+    int eob = 0, ntab = 0, nsel = 0;
+    do {
+        // block header, S/BZip2BlockDecompressor.swift:474-477
+        crc = br.bits(16) << 16;
+        crc |= br.bits(16);
+        const u32 randomised = br.bits(1);
+        orig = br.bits(24);
+        if (br.over()) { status = KS_INSUFFICIENT; break; }
+        if (randomised) { status = KS_RANDOMISED; break; }
+        // symbol map, :203-221
+        int nsym = 0;
+        const u32 ranges = br.bits(16);
+        for (int i = 0; i < 16; i++) {
+            if (ranges & (0x8000u >> i)) {
+                const u32 m = br.bits(16);
+                for (int j = 0; j < 16; j++)
+                    if (m & (0x8000u >> j)) symmap[nsym++] = (u8)(i * 16 + j);
+            }
+        }
+        if (br.over()) { status = KS_INSUFFICIENT; break; }
+        eob = nsym + 1;
+        ntab = (int)br.bits(3);
+        nsel = (int)br.bits(15);
+        if (br.over()) { status = KS_INSUFFICIENT; break; }
+        if (ntab < 2 || ntab > 6 || nsel < 1 || nsel > SEL_MAX - 1) { status = KS_TABLES; break; }
+        // selectors: unary, MTF over the table indices, :238-243
+        for (int i = 0; i < nsel && status == KS_OK; i++) {
+            int u = 0;
+            for (;;) {
+                br.fill();
+                // leading ones of the buffer (at least 57 valid bits)
+                const int ones = (~br.bb) ? __clzll((long long)~br.bb) : 64;
+                if (ones < br.bc) { u += ones; br.skip(ones + 1); break; }
+                u += br.bc;
+                br.skip(br.bc);
+                if (br.over()) { status = KS_INSUFFICIENT; break; }
+            }
+            if (status != KS_OK) break;
+            u &= 255;
+            const u8 v = tmtf[u];
+            for (int j = u; j > 0; j--) tmtf[j] = tmtf[j - 1];
+            tmtf[0] = v;
+            sel[i] = v;
+        }
+        if (status != KS_OK) break;
+        if (br.over()) { status = KS_INSUFFICIENT; break; }
+        // delta-coded code lengths, :246-254
+        for (int t = 0; t < ntab && status == KS_OK; t++) {
+            int cur = (int)br.bits(5);
+            for (int i = 0; i <= eob; i++) {
+                for (;;) {
+                    br.fill();
+                    if (!br.peek(1)) { br.skip(1); break; }
+                    cur += (br.peek(2) & 1u) ? -1 : 1;
+                    br.skip(2);
+                    if (br.over()) break;
+                }
+                if (br.over()) { status = KS_INSUFFICIENT; break; }
+                if (cur < 0 || cur > KD_MAXLEN) { status = KS_TABLES; break; }
+                lens[t][i] = (u8)cur;
+            }
+        }
+        if (status != KS_OK) break;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        // canonical decode tables, S/BZip2HuffmanStageDecoder.swift:84-141
+        const int alpha = eob + 1;
+        for (int t = 0; t < ntab; t++) {
+            int mn = KD_MAXLEN, mx = 0;
+            for (int i = 0; i < alpha; i++) {
+                const int l = lens[t][i];
+                mx = max(mx, l);
+                mn = min(mn, l);
+            }
+            minlen[t] = mn;
+            for (int i = 0; i < alpha; i++) bases[t][lens[t][i] + 1]++;
+            for (int i = 1; i < KD_MAXLEN + 2; i++) bases[t][i] += bases[t][i - 1];
+            int code = 0;
+            for (int i = mn; i <= mx; i++) {
+                const int base = code;
+                code += bases[t][i + 1] - bases[t][i];
+                bases[t][i] = base - bases[t][i];
+                limits[t][i] = code - 1;
+                code <<= 1;
+            }
+            int ci = 0;
+            for (int bl = mn; bl <= mx; bl++)
+                for (int sy = 0; sy < alpha; sy++)
+                    if (lens[t][sy] == bl) symbols[t][ci++] = (u16)sy;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        // symbols -> BWT bytes, S/BZip2BlockDecompressor.swift:266-321
+        u32 L = (u32)lane * 4u;
+        L = L | ((L + 1) << 8) | ((L + 2) << 16) | ((L + 3) << 24);
+        u32 rep = 0, inc = 1, mtfv = 0;
+        int gpos = -1, gidx = -1, cur = sel[0];
+        for (;;) {
+            gpos++;
+            if (gpos % GROUP == 0) {
+                gidx++;
+                if (gidx == nsel) { status = KS_DECODE; break; }
+                cur = sel[gidx];
+                if (cur >= 6) { status = KS_DECODE; break; }
+            }
+            br.fill();
+            int cl = minlen[cur];
+            int sym = -1;
+            while (cl <= KD_MAXLEN) {
+                const int code = (int)br.peek(cl);
+                if (code <= limits[cur][cl]) {
+                    const int ix = code - bases[cur][cl];
+                    if (ix >= 0 && ix < MAX_ALPHA) sym = symbols[cur][ix];
+                    break;
+                }
+                cl++;
+            }
+            br.skip(min(cl, KD_MAXLEN + 1));
+            if (br.over()) { status = KS_INSUFFICIENT; break; }
+            if (sym < 0) { status = KS_DECODE; break; }
+            if (sym == 0) {
+                rep += inc;
+                inc <<= 1;
+            } else if (sym == 1) {
+                rep += inc << 1;
+                inc <<= 1;
+            } else {
+                if (rep > 0) {
+                    if (len + rep > block_size) { status = KS_BLOCK_SIZE; break; }
+                    const u8 byte = symmap[mtfv];
+                    for (u32 q = lane; q < rep; q += 64) out[len + q] = byte;
+                    len += rep;
+                    rep = 0;
+                    inc = 1;
+                }
+                if (sym == eob) break;
+                if (len >= block_size) { status = KS_BLOCK_SIZE; break; }
+                mtfv = kd_index_to_front(L, (u32)(sym - 1) & 255u);
+                out[len++] = symmap[mtfv];
+            }
+            if (rep > 2u * 900000u + 2u) { status = KS_BLOCK_SIZE; break; }
+        }
+    } while (0);
+    if (lane == 0) {
+        const u64 e = br.consumed();
+        mt[KM_STATUS] = status;
+        mt[KM_N] = len;
+        mt[KM_ORIG] = orig;
+        mt[KM_CRC] = crc;
+        mt[KM_END_LO] = (u32)e;
+        mt[KM_END_HI] = (u32)(e >> 32);
+    }
+}
+
+// ------------------------------------------------------------------ inverse BWT
+// per-block list of the slots to work on: slot[k] = candidate index, nArr / orig per chain block
+__global__ __launch_bounds__(256) void kd_hist(const u8 *__restrict__ bwt, const u32 *__restrict__ slot,
+                                               const u32 *__restrict__ nArr, u32 S,
+                                               u32 *__restrict__ base) {
+    const u32 b = blockIdx.x;
+    __shared__ u32 h[256];
+    __shared__ u32 sm[8];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const u8 *p = bwt + (size_t)slot[b] * S;
+    const u32 n = nArr[b];
+    for (u32 i = threadIdx.x; i < n; i += 256) atomicAdd(&h[p[i]], 1u);
+    __syncthreads();
+    u32 tot;
+    const u32 ex = block_excl_scan_add<256>(h[threadIdx.x], sm, &tot);
+    base[(size_t)b * 256 + threadIdx.x] = ex;
+}
+
+// merged[base[v]++] = (i << 8) + v in index order (S/BZip2BlockDecompressor.swift:346-350); one wave
+__global__ __launch_bounds__(64) void kd_merge(const u8 *__restrict__ bwt, const u32 *__restrict__ slot,
+                                               const u32 *__restrict__ nArr, u32 S,
+                                               const u32 *__restrict__ base, u32 *__restrict__ merged) {
+    const u32 b = blockIdx.x;
+    const int lane = lane_id();
+    __shared__ u32 run[256];
+    for (int q = lane; q < 256; q += 64) run[q] = base[(size_t)b * 256 + q];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    const u8 *p = bwt + (size_t)slot[b] * S;
+    u32 *mg = merged + (size_t)b * S;
+    const u32 n = nArr[b];
+    const u64 lt = (1ull << lane) - 1ull;
+    for (u32 r0 = 0; r0 < n; r0 += 256) {
+        u32 vv[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u32 i = r0 + k * 64 + lane;
+            vv[k] = (i < n) ? p[i] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u32 i = r0 + k * 64 + lane;
+            const bool act = i < n;
+            const u32 v = vv[k];
+            u64 m = __ballot(act);
+#pragma unroll
+            for (int bit = 0; bit < 8; bit++) {
+                const bool s = (v >> bit) & 1u;
+                const u64 bm = __ballot(s);
+                m &= s ? bm : ~bm;
+            }
+            if (act) {
+                const u32 rk = (u32)__popcll(m & lt);
+                const u32 bs = run[v];
+                mg[bs + rk] = (i << 8) + v;
+                if (rk == 0) run[v] = bs + (u32)__popcll(m);
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+__device__ __forceinline__ bool kd_is_ruler(u32 x, u32 orig) { return (x % KD_RULER) == 0 || x == orig; }
+__device__ __forceinline__ u32 kd_ruler_id(u32 x, u32 orig, u32 NR) {
+    return (x % KD_RULER) == 0 ? x / KD_RULER : NR; // the origin, when it is not a regular ruler
+}
+
+// a) every ruler walks to the next ruler: rinfo[id] = {next ruler id, steps}
+__global__ __launch_bounds__(256) void kd_walk_a(const u32 *__restrict__ merged,
+                                                 const u32 *__restrict__ nArr,
+                                                 const u32 *__restrict__ origArr, u32 S, u32 RS,
+                                                 uint2 *__restrict__ rinfo) {
+    const u32 b = blockIdx.y;
+    const u32 n = nArr[b], orig = origArr[b];
+    if (n == 0) return;
+    const u32 NR = (n + KD_RULER - 1) / KD_RULER;
+    const u32 id = blockIdx.x * 256 + threadIdx.x;
+    if (id > NR) return;
+    u32 x;
+    if (id < NR) x = id * KD_RULER;
+    else {
+        if (orig % KD_RULER == 0) return;
+        x = orig;
+    }
+    const u32 *mg = merged + (size_t)b * S;
+    u32 steps = 0;
+    do {
+        x = mg[x] >> 8;
+        steps++;
+    } while (!kd_is_ruler(x, orig) && steps < n);
+    rinfo[(size_t)b * RS + id] = make_uint2(kd_ruler_id(x, orig, NR), steps);
+}
+
+// b) one lane per block: the ruler chain from the origin; visits[k] = {ruler id, output offset}
+__global__ void kd_walk_b(const u32 *__restrict__ nArr, const u32 *__restrict__ origArr, u32 RS,
+                          const uint2 *__restrict__ rinfo, uint2 *__restrict__ visits,
+                          u32 *__restrict__ nvis, u32 *__restrict__ cyc, u32 nb) {
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const u32 n = nArr[b], orig = origArr[b];
+    if (n == 0) { nvis[b] = 0; cyc[b] = 0; return; }
+    const u32 NR = (n + KD_RULER - 1) / KD_RULER;
+    const u32 start = kd_ruler_id(orig, orig, NR);
+    const uint2 *ri = rinfo + (size_t)b * RS;
+    uint2 *vs = visits + (size_t)b * RS;
+    u32 off = 0, r = start, v = 0;
+    do {
+        vs[v++] = make_uint2(r, off);
+        const uint2 e = ri[r];
+        off += e.y;
+        r = e.x;
+    } while (off < n && r != start && v < RS);
+    nvis[b] = v;
+    cyc[b] = min(off, n); // < n: the walk closed early (block = w^k); the rest repeats
+}
+
+// c) every visited ruler walks again and writes its bytes
+__global__ __launch_bounds__(256) void kd_walk_c(const u32 *__restrict__ merged,
+                                                 const u32 *__restrict__ nArr,
+                                                 const u32 *__restrict__ origArr, u32 S, u32 RS,
+                                                 const uint2 *__restrict__ rinfo,
+                                                 const uint2 *__restrict__ visits,
+                                                 const u32 *__restrict__ nvis,
+                                                 const u32 *__restrict__ cyc, u8 *__restrict__ tt) {
+    const u32 b = blockIdx.y;
+    const u32 k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= nvis[b]) return;
+    const u32 n = nArr[b], orig = origArr[b];
+    const u32 NR = (n + KD_RULER - 1) / KD_RULER;
+    const uint2 vi = visits[(size_t)b * RS + k];
+    const u32 steps = rinfo[(size_t)b * RS + vi.x].y;
+    u32 x = (vi.x < NR) ? vi.x * KD_RULER : orig;
+    const u32 *mg = merged + (size_t)b * S;
+    u8 *o = tt + (size_t)b * S;
+    const u32 lim = cyc[b];
+    for (u32 t = 0; t < steps; t++) {
+        const u32 m = mg[x];
+        if (vi.y + t < lim) o[vi.y + t] = (u8)(m & 0xffu);
+        x = m >> 8;
+    }
+}
+
+__global__ __launch_bounds__(256) void kd_cycfill(const u32 *__restrict__ nArr,
+                                                  const u32 *__restrict__ cyc, u32 S,
+                                                  u8 *__restrict__ tt) {
+    const u32 b = blockIdx.y;
+    const u32 n = nArr[b], c = cyc[b];
+    if (c == 0 || c >= n) return;
+    u8 *o = tt + (size_t)b * S;
+    for (u32 t = c + blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) o[t] = o[t % c];
+}
+
+// ------------------------------------------------------------------ final run-length decoding
+// S/BZip2BlockDecompressor.swift:386-420.  After four equal bytes the next byte is a repeat count.
+// Over a run of L equal bytes entered with s = "its first byte is a count", the pattern is
+// [count] d d d d c d d d d c ...: byte k of the run is a count iff k >= s and (k - s) % 5 == 4, or
+// k == 0 and s == 1; the next run starts with a count iff (L - s) % 5 == 4.  That is a two-state
+// automaton over runs: each run end carries the function s -> s', composed by a wave scan.
+__device__ __forceinline__ u32 kd_fcompose(u32 a, u32 b) { // a earlier, b later; bit s = image of s
+    return ((b >> (a & 1u)) & 1u) | (((b >> ((a >> 1) & 1u)) & 1u) << 1);
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(64) void kd_unrle(const u8 *__restrict__ tt, const u32 *__restrict__ nArr,
+                                               u32 S, u32 *__restrict__ outlen,
+                                               u32 *__restrict__ flags, const u32 *__restrict__ outbase,
+                                               u8 *__restrict__ out) {
+    const u32 b = blockIdx.x;
+    const int lane = lane_id();
+    const u32 n = nArr[b];
+    const u8 *p = tt + (size_t)b * S;
+    u8 *o = WRITE ? out + outbase[b] : nullptr;
+    u32 carry_prev = 256, carry_rs = 0, s_in = 0;
+    u32 off = 0;
+    bool overflow = false;
+    for (u32 rowbase = 0; rowbase < n; rowbase += 64) {
+        const u32 t = rowbase + lane;
+        const bool act = t < n;
+        const u32 v = act ? p[t] : 0u;
+        const u32 nxt = (t + 1 < n) ? p[t + 1] : 256u;
+        u32 pv = __shfl_up(v, 1, 64);
+        if (lane == 0) pv = carry_prev;
+        const bool head = act && (t == 0 || v != pv);
+        u32 hs = head ? t + 1 : 0u;
+        hs = wave_incl_scan_max(hs);
+        const u32 rs = max(hs, carry_rs + 1) - 1; // start of the run this byte belongs to
+        const bool end = act && (nxt != v);
+        const u32 Lr = t - rs + 1;
+        u32 F = 2u; // identity
+        if (end) F = ((Lr % 5u) == 4u ? 1u : 0u) | (((Lr - 1u) % 5u) == 4u ? 2u : 0u);
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 e = __shfl_up(F, d, 64);
+            if (lane >= d) F = kd_fcompose(e, F);
+        }
+        u32 Fx = __shfl_up(F, 1, 64);
+        if (lane == 0) Fx = 2u;
+        const u32 s_run = (Fx >> s_in) & 1u;
+        const u32 k = t - rs;
+        const bool is_count = act && ((s_run == 1u && k == 0u) || (k >= s_run && ((k - s_run) % 5u) == 4u));
+        const u32 contrib = act ? (is_count ? v : 1u) : 0u;
+        const u32 inc = wave_incl_scan_add(contrib);
+        const u32 tot = __shfl(inc, 63, 64);
+        if (off + tot < off) overflow = true;
+        if (WRITE) {
+            const u32 my = off + inc - contrib;
+            if (act && !is_count) o[my] = (u8)v;
+            // a count: the whole wave writes its copies
+            u64 cm = __ballot(is_count && v > 0);
+            while (cm) {
+                const int i = __ffsll((unsigned long long)cm) - 1;
+                cm &= cm - 1;
+                const u32 cnt = __shfl(v, i, 64), at = __shfl(my, i, 64), byte = __shfl(pv, i, 64);
+                for (u32 q = lane; q < cnt; q += 64) o[at + q] = (u8)byte;
+            }
+        }
+        off += tot;
+        s_in = (__shfl(F, 63, 64) >> s_in) & 1u;
+        carry_prev = __shfl(v, 63, 64);
+        carry_rs = __shfl(rs, 63, 64);
+    }
+    if (!WRITE && lane == 0) {
+        outlen[b] = off;
+        flags[b] = (s_in ? 1u : 0u) | (overflow ? 2u : 0u); // 1: the block ends where a count is due
+    }
+}
+
+// ------------------------------------------------------------------ host driver
+namespace {
+struct DevBuf {
+    std::vector<void *> v;
+    ~DevBuf() { for (void *p : v) (void)hipFree(p); }
+    template <typename T> T *get(size_t count) {
+        void *p = nullptr;
+        HIPCHK(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+        v.push_back(p);
+        return (T *)p;
+    }
+};
+int map_status(u32 s) {
+    switch (s) {
+    case KS_INSUFFICIENT: return BZ2HIP_E_INSUFFICIENT;
+    case KS_TABLES: return BZ2HIP_E_TABLES;
+    case KS_BLOCK_SIZE: return BZ2HIP_E_BLOCK_SIZE;
+    case KS_DECODE: return BZ2HIP_E_DECODE;
+    case KS_RANDOMISED: return BZ2HIP_E_RANDOMISED;
+    default: return BZ2HIP_OK;
+    }
+}
+// big-endian bits [bit, bit + count) of a host copy of the stream; count <= 32
+bool host_bits(const std::vector<u8> &buf, u64 buf_bit0, u64 nbits_total, u64 bit, int count, u32 *out) {
+    if (bit + (u64)count > nbits_total) return false;
+    u64 v = 0;
+    const u64 rel = bit - buf_bit0;
+    for (int q = 0; q < 8; q++) {
+        const u64 idx = (rel >> 3) + q;
+        v = (v << 8) | (idx < buf.size() ? buf[idx] : 0);
+    }
+    *out = (u32)((v << (rel & 7)) >> (64 - count));
+    return true;
+}
+} // namespace
+
+// Decodes the stream at d_in into d_out.  Returns BZ2HIP_OK or the first error the reference would
+// have thrown; *produced = bytes it would have handed out before that (written to d_out).
+int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size_t cap, size_t *produced,
+                   u32 *blocks_out) {
+    *produced = 0;
+    if (blocks_out) *blocks_out = 0;
+    hipStream_t st = c->stream;
+    const u64 total_bits = (u64)nbytes * 8u;
+    // stream header, S/BZip2InputStream.swift:166-180
+    u8 hdr[4] = {0, 0, 0, 0};
+    if (nbytes < 4) { c->err = "Insufficient data"; return BZ2HIP_E_INSUFFICIENT; }
+    HIPCHK(hipMemcpyAsync(hdr, d_in, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const int level = (int)hdr[3] - '0';
+    if (hdr[0] != 'B' || hdr[1] != 'Z' || hdr[2] != 'h' || level < 1 || level > 9) {
+        c->err = "Invalid BZip2 header";
+        return BZ2HIP_E_HEADER;
+    }
+    const u32 block_size = (u32)level * 100000u;
+    const u32 S = ((block_size + 64 + RTILE - 1) / RTILE) * RTILE;
+
+    DevBuf D;
+    // candidates: a block is at least ~ 80 bits long; the scan keeps what fits and reports overflow
+    const u32 cand_cap = (u32)std::min<u64>(nbytes / 8 + 16, 1u << 22);
+    u64 *d_cand = D.get<u64>(cand_cap);
+    u32 *d_ncand = D.get<u32>(4);
+    HIPCHK(hipMemsetAsync(d_ncand, 0, 16, st));
+    kd_scan_magic<<<(u32)((nbytes + 255) / 256), 256, 0, st>>>(d_in, nbytes, d_cand, d_ncand, cand_cap);
+    KCHECK();
+    u32 ncand = 0;
+    HIPCHK(hipMemcpyAsync(&ncand, d_ncand, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (ncand > cand_cap) throw HipError(BZ2HIP_E_NOMEM, "too many block magic candidates");
+    std::vector<u64> cand(ncand);
+    if (ncand) {
+        HIPCHK(hipMemcpyAsync(cand.data(), d_cand, ncand * sizeof(u64), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        std::sort(cand.begin(), cand.end());
+        HIPCHK(hipMemcpyAsync(d_cand, cand.data(), ncand * sizeof(u64), hipMemcpyHostToDevice, st));
+    }
+    // the tail of the stream on the host (end marker + stored CRC are read there)
+    std::vector<u32> meta((size_t)ncand * KM_WORDS);
+    u8 *d_bwt = D.get<u8>((size_t)std::max(ncand, 1u) * S);
+    if (ncand) {
+        u32 *d_meta = D.get<u32>((size_t)ncand * KM_WORDS);
+        kd_huff<<<ncand, 64, 0, st>>>(d_in, nbytes, d_cand, block_size, S, d_bwt, d_meta);
+        KCHECK();
+        HIPCHK(hipMemcpyAsync(meta.data(), d_meta, meta.size() * sizeof(u32), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    // chain walk, S/BZip2InputStream.swift:201-242
+    std::vector<u32> chain;   // candidate index of block k
+    int rc = BZ2HIP_OK;       // error that ends the stream after the chain's blocks
+    const char *msg = "";
+    bool have_trailer = false;
+    u32 stored_stream_crc = 0;
+    u64 cur = 32;
+    for (;;) {
+        auto it = std::lower_bound(cand.begin(), cand.end(), cur);
+        if (it != cand.end() && *it == cur) {
+            const u32 ci = (u32)(it - cand.begin());
+            const u32 *mt = &meta[(size_t)ci * KM_WORDS];
+            if (mt[KM_STATUS] != KS_OK) {
+                rc = map_status(mt[KM_STATUS]);
+                msg = "block could not be decoded";
+                break;
+            }
+            chain.push_back(ci);
+            cur = (u64)mt[KM_END_LO] | ((u64)mt[KM_END_HI] << 32);
+            continue;
+        }
+        // not a block: end marker or garbage
+        std::vector<u8> tail(16, 0);
+        const u64 byte0 = cur >> 3;
+        const size_t avail = byte0 < nbytes ? std::min<size_t>(16, nbytes - byte0) : 0;
+        if (avail) {
+            HIPCHK(hipMemcpyAsync(tail.data(), d_in + byte0, avail, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+        }
+        tail.resize(avail);
+        u32 m1 = 0, m2 = 0;
+        if (!host_bits(tail, byte0 * 8, total_bits, cur, 24, &m1) ||
+            !host_bits(tail, byte0 * 8, total_bits, cur + 24, 24, &m2)) {
+            rc = BZ2HIP_E_INSUFFICIENT;
+            msg = "Insufficient data";
+        } else if (m1 == 0x177245u && m2 == 0x385090u) {
+            if (!host_bits(tail, byte0 * 8, total_bits, cur + 48, 32, &stored_stream_crc)) {
+                rc = BZ2HIP_E_INSUFFICIENT;
+                msg = "Insufficient data";
+            } else have_trailer = true;
+        } else {
+            rc = BZ2HIP_E_FORMAT;
+            msg = "BZip2 stream format error";
+        }
+        break;
+    }
+    const u32 nb = (u32)chain.size();
+    if (blocks_out) *blocks_out = nb;
+    u32 stream_crc = 0;
+    if (nb) {
+        std::vector<u32> h_slot(nb), h_n(nb), h_orig(nb), h_crc(nb);
+        u32 maxn = 0;
+        u32 first_bad_ptr = nb; // S/BZip2BlockDecompressor.swift:332-334
+        for (u32 k = 0; k < nb; k++) {
+            const u32 *mt = &meta[(size_t)chain[k] * KM_WORDS];
+            h_slot[k] = chain[k];
+            h_n[k] = mt[KM_N];
+            h_orig[k] = mt[KM_ORIG];
+            h_crc[k] = mt[KM_CRC];
+            if (h_orig[k] >= h_n[k] && first_bad_ptr == nb) first_bad_ptr = k;
+            if (h_orig[k] >= h_n[k]) { h_n[k] = 0; h_orig[k] = 0; }
+            maxn = std::max(maxn, h_n[k]);
+        }
+        const u32 RS = (maxn + KD_RULER - 1) / KD_RULER + 2;
+        u32 *d_slot = D.get<u32>(nb), *d_n = D.get<u32>(nb), *d_orig = D.get<u32>(nb);
+        u32 *d_base = D.get<u32>((size_t)nb * 256);
+        u32 *d_merged = D.get<u32>((size_t)nb * S);
+        u8 *d_tt = D.get<u8>((size_t)nb * S);
+        uint2 *d_rinfo = D.get<uint2>((size_t)nb * RS), *d_visits = D.get<uint2>((size_t)nb * RS);
+        u32 *d_nvis = D.get<u32>(nb), *d_cyc = D.get<u32>(nb);
+        u32 *d_outlen = D.get<u32>(nb), *d_flags = D.get<u32>(nb), *d_outbase = D.get<u32>(nb + 1);
+        HIPCHK(hipMemcpyAsync(d_slot, h_slot.data(), nb * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(d_n, h_n.data(), nb * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(d_orig, h_orig.data(), nb * 4, hipMemcpyHostToDevice, st));
+        if (maxn) {
+            kd_hist<<<nb, 256, 0, st>>>(d_bwt, d_slot, d_n, S, d_base);
+            KCHECK();
+            kd_merge<<<nb, 64, 0, st>>>(d_bwt, d_slot, d_n, S, d_base, d_merged);
+            KCHECK();
+            const dim3 gr((RS + 255) / 256, nb);
+            kd_walk_a<<<gr, 256, 0, st>>>(d_merged, d_n, d_orig, S, RS, d_rinfo);
+            KCHECK();
+            kd_walk_b<<<(nb + 63) / 64, 64, 0, st>>>(d_n, d_orig, RS, d_rinfo, d_visits, d_nvis, d_cyc, nb);
+            KCHECK();
+            kd_walk_c<<<gr, 256, 0, st>>>(d_merged, d_n, d_orig, S, RS, d_rinfo, d_visits, d_nvis, d_cyc, d_tt);
+            KCHECK();
+            kd_cycfill<<<dim3(64, nb), 256, 0, st>>>(d_n, d_cyc, S, d_tt);
+            KCHECK();
+        }
+        kd_unrle<false><<<nb, 64, 0, st>>>(d_tt, d_n, S, d_outlen, d_flags, nullptr, nullptr);
+        KCHECK();
+        std::vector<u32> h_outlen(nb), h_flags(nb);
+        HIPCHK(hipMemcpyAsync(h_outlen.data(), d_outlen, nb * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(h_flags.data(), d_flags, nb * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        // blocks the reference would have handed out: up to the first one it fails on
+        u32 good = nb; // blocks [0, good) are expanded
+        int rc2 = BZ2HIP_OK;
+        const char *msg2 = "";
+        for (u32 k = 0; k < nb; k++) {
+            if (k == first_bad_ptr) { good = k; rc2 = BZ2HIP_E_START_PTR; msg2 = "BZip2 start pointer invalid"; break; }
+            if (h_flags[k] & 1u) { good = k; rc2 = BZ2HIP_E_FORMAT; msg2 = "block ends where a repeat count is due"; break; }
+        }
+        // ... and that fit: the reference stops at the first block whose CRC fails, so a damaged
+        // block that decodes to something huge must not turn into a capacity error of a later one
+        bool cap_hit = false;
+        std::vector<u32> h_base(1, 0);
+        u64 total = 0;
+        u32 maxlen = 0;
+        for (u32 k = 0; k < good; k++) {
+            if (total + h_outlen[k] > cap || total + h_outlen[k] > 0xfffffff0ull || (h_flags[k] & 2u)) {
+                cap_hit = true;
+                good = k;
+                break;
+            }
+            total += h_outlen[k];
+            maxlen = std::max(maxlen, h_outlen[k]);
+            h_base.push_back((u32)total);
+        }
+        u32 crc_fail = good;
+        if (good) {
+            HIPCHK(hipMemcpyAsync(d_outbase, h_base.data(), (good + 1) * 4, hipMemcpyHostToDevice, st));
+            kd_unrle<true><<<good, 64, 0, st>>>(d_tt, d_n, S, nullptr, nullptr, d_outbase, d_out);
+            KCHECK();
+            const u32 ETPB = (maxlen + 4095) / 4096 + 1;
+            u32 *d_cagg = D.get<u32>((size_t)good * ETPB), *d_crc = D.get<u32>(good);
+            run_crc_blocks(c, d_out, d_outbase, (int)good, maxlen, d_cagg, ETPB, d_crc);
+            std::vector<u32> got(good);
+            HIPCHK(hipMemcpyAsync(got.data(), d_crc, good * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            for (u32 k = 0; k < good; k++) {
+                if (got[k] != h_crc[k]) { crc_fail = k; break; }
+                stream_crc = ((stream_crc << 1) | (stream_crc >> 31)) ^ h_crc[k];
+            }
+        }
+        if (crc_fail < good) {
+            // the block's bytes are out before its CRC is compared (S/BZip2InputStream.swift:209-212)
+            *produced = h_base[crc_fail + 1];
+            c->err = "BZip2 block CRC error";
+            return BZ2HIP_E_BLOCK_CRC;
+        }
+        *produced = (size_t)total;
+        if (cap_hit) { c->err = "output buffer too small"; return BZ2HIP_E_CAP; }
+        if (rc2 != BZ2HIP_OK) { c->err = msg2; return rc2; }
+    }
+    if (rc != BZ2HIP_OK) { c->err = msg; return rc; }
+    if (have_trailer && stored_stream_crc != stream_crc) {
+        c->err = "BZip2 stream CRC error";
+        return BZ2HIP_E_STREAM_CRC;
+    }
+    return BZ2HIP_OK;
+}

@@ -27,6 +27,17 @@ extern "C" {
 #define BZ2HIP_E_HIP (-3)     /* a HIP runtime call failed */
 #define BZ2HIP_E_CAP (-4)     /* caller's output buffer too small */
 #define BZ2HIP_E_STATE (-5)   /* call sequence error, e.g. write after finish */
+/* decoder: the reference's exceptions, in the order it would throw them */
+#define BZ2HIP_E_INSUFFICIENT (-6) /* "Insufficient data"            S/BZip2BitInputStream.swift:63,92,123 */
+#define BZ2HIP_E_HEADER (-7)       /* "Invalid BZip2 header"         S/BZip2InputStream.swift:177 */
+#define BZ2HIP_E_FORMAT (-8)       /* "BZip2 stream format error"    S/BZip2InputStream.swift:240 */
+#define BZ2HIP_E_BLOCK_CRC (-9)    /* "BZip2 block CRC error"        S/BZip2BlockDecompressor.swift:456 */
+#define BZ2HIP_E_STREAM_CRC (-10)  /* "BZip2 stream CRC error"       S/BZip2InputStream.swift:233 */
+#define BZ2HIP_E_TABLES (-11)      /* "BZip2 block Huffman tables invalid"       S/BZip2BlockDecompressor.swift:235 */
+#define BZ2HIP_E_BLOCK_SIZE (-12)  /* "BZip2 block exceeds declared block size"  :288,:307 */
+#define BZ2HIP_E_START_PTR (-13)   /* "BZip2 start pointer invalid"              :333 */
+#define BZ2HIP_E_DECODE (-14)      /* "Error decoding BZip2 block"   S/BZip2HuffmanStageDecoder.swift:158,179 */
+#define BZ2HIP_E_RANDOMISED (-15)  /* randomised block (S/BZip2BlockDecompressor.swift:367-374): not supported */
 
 #define BZ2HIP_MAX_ALPHA 258
 #define BZ2HIP_MAX_TABLES 6
@@ -142,6 +153,19 @@ int bz2hip_block_compress(bz2hip_ctx *ctx, const uint8_t *rle_blocks, const uint
                           uint32_t count, uint32_t stride, const uint8_t *present,
                           const uint32_t *crc, uint8_t *bits, size_t bits_stride,
                           uint64_t *nbits);
+
+/* ---- Decoder.  Replaces BZip2InputStream.read(...) over a whole stream
+ * (S/BZip2InputStream.swift:91-128,154-242) and the classes under it (BZip2BlockDecompressor,
+ * BZip2HuffmanStageDecoder, BZip2BitInputStream): all blocks are decoded at once on the GPU.
+ * in = one complete .bz2 stream ("BZh" + level ...; bytes after the end marker are ignored as the
+ * reference ignores them).  Returns BZ2HIP_OK or the first error the reference would throw;
+ * *produced = the bytes it would have handed out before that, written to out (a block's bytes are
+ * out before its CRC is compared).  BZ2HIP_E_CAP: a block did not fit in cap (*produced = the blocks
+ * before it).  The _device form takes device pointers. */
+int bz2hip_decompress(bz2hip_ctx *ctx, const uint8_t *in, size_t n, uint8_t *out, size_t cap,
+                      size_t *produced);
+int bz2hip_decompress_device(bz2hip_ctx *ctx, const void *d_in, size_t n, void *d_out, size_t cap,
+                             size_t *produced);
 
 /* ---- profiling (profile=1): accumulated HIP-event time per kernel class --------------- */
 #define BZ2HIP_PROF_MAX 48

@@ -138,7 +138,7 @@ static int decode_block_to_bwt(bitin_t *s, int block_size, uint8_t *bwt, int *n_
     if (s->err) return s->err;
     if (randomised) return ORC_D_RANDOMISED;
 
-    uint8_t symmap[256];
+    uint8_t symmap[256] = {0}; /* Array(repeating: 0, count: 256), S/BZip2BlockDecompressor.swift:119 */
     int nsym = 0;
     uint32_t ranges = read_bits(s, 16);
     for (int i = 0; i < 16; i++)

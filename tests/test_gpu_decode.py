@@ -1,0 +1,95 @@
+"""GPU decoder (kd_decode.hip) against the decoder oracle and libbz2, through the
+C ABI.  Bit-exact bytes; error codes and the number of bytes handed out before the error follow the
+oracle (= the reference's order of checks)."""
+import bz2
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, ROOT)
+import orc  # noqa: E402
+from bzip2_amd import corpus  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+# oracle code -> C ABI code
+MAP = {0: 0, -1: -6, -2: -7, -3: -8, -4: -9, -5: -10, -6: -11, -7: -12, -8: -13, -9: -14, -10: -15, -11: -4}
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from bzip2_amd import Context
+    c = Context()
+    yield c
+    c.close()
+
+
+def _inputs():
+    rng = np.random.default_rng(7)
+    yield "empty", b""
+    yield "one", b"x"
+    yield "text", corpus.text(300000, 1).tobytes()
+    yield "random", rng.integers(0, 256, 250000, dtype=np.uint8).tobytes()
+    yield "runs", (b"a" * 1000 + b"b" * 4 + b"c" * 5 + b"d" * 259 + b"e" * 3) * 300
+    yield "zeros", bytes(3 << 20)
+    yield "ff255", b"\xff" * 255 * 40
+    yield "mixed", corpus.mixed(3, 99).tobytes()
+    yield "count_eq_byte", (b"\x05" * 9 + b"\x00" * 4 + b"\x04" * 8) * 1000
+    yield "abab", b"ab" * 300000
+    yield "fours", bytes(np.repeat(rng.integers(0, 256, 200000, dtype=np.uint8), 4))
+
+
+@pytest.mark.parametrize("name,data", list(_inputs()), ids=[n for n, _ in _inputs()])
+@pytest.mark.parametrize("level", [1, 9])
+def test_decode_equals_libbz2(ctx, name, data, level):
+    for stream in (bz2.compress(data, level), ctx.compress(data, level)):
+        rc, out = ctx.decompress(stream, len(data) + 16)
+        assert rc == 0
+        assert out == data
+
+
+def test_large_roundtrip(ctx):
+    data = corpus.mixed(32, 1234).tobytes()
+    stream = ctx.compress(data, 9)
+    rc, out = ctx.decompress(stream, len(data))
+    assert rc == 0 and out == data
+    rc, out = ctx.decompress(stream, len(data) - 1)
+    assert rc == -4 and len(out) > 0 and out == data[:len(out)]
+
+
+def test_errors_follow_the_oracle(ctx):
+    data = corpus.mixed(1, 3).tobytes()[:350000]
+    s = bz2.compress(data, 1)
+    cap = len(data) + 16
+    cases = [s[:3], b"CZh9" + s[4:], s[:3] + b"0" + s[4:], s + b"garbage", s[:len(s) // 2], s[:-3], s[:-11]]
+    for pos, bit in ((5, 1), (11, 0x10), (len(s) - 2, 0x40), (20, 1), (40, 0x80), (len(s) // 2, 4), (15, 2)):
+        bad = bytearray(s)
+        bad[pos] ^= bit
+        cases.append(bytes(bad))
+    for k, st in enumerate(cases):
+        orc_rc, orc_out, _ = orc.decompress(st, cap)
+        rc, out = ctx.decompress(st, cap)
+        assert rc == MAP[orc_rc], (k, rc, orc_rc)
+        assert out == orc_out, k
+
+
+def test_bit_flip_fuzz(ctx):
+    rng = np.random.default_rng(5)
+    data = corpus.mixed(1, 8).tobytes()[:250000]
+    s = bz2.compress(data, 1)
+    cap = len(data) * 2
+    for k in range(150):
+        bad = bytearray(s)
+        for _ in range(int(rng.integers(1, 3))):
+            bad[int(rng.integers(4, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+        orc_rc, orc_out, _ = orc.decompress(bytes(bad), cap)
+        rc, out = ctx.decompress(bytes(bad), cap)
+        if orc_rc == orc.D_CAPACITY:
+            assert rc == -4
+            continue
+        assert rc == MAP[orc_rc], (k, rc, orc_rc)
+        assert out == orc_out, k
