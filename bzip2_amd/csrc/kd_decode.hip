@@ -76,62 +76,73 @@ __device__ __forceinline__ u32 kd_index_to_front(u32 &L, u32 p) {
     return v;
 }
 
+// MSB-first bit reader over an LDS window of the stream, refilled 32 bits at a time (window words
+// are aligned to stream offsets that are multiples of 4, whatever the pointer's alignment)
 struct KdBits {
     const u8 *in;
-    u64 nbytes, pos, wbase; // pos = next byte to enter the bit buffer; window = [wbase, wbase + KD_WIN)
-    u64 bb;                 // bit buffer, MSB first
-    int bc;                 // valid bits in bb
-    u8 *win;
-    __device__ __forceinline__ void load_window(u64 at) {
-        wbase = at;
+    u64 nbytes, wpos, wbase; // wpos = next stream word (4 bytes) to enter the buffer; window = [wbase, wbase + KD_WIN/4)
+    u64 bb;                  // bit buffer, MSB first
+    int bc;                  // valid bits in bb
+    u32 *win;
+    __device__ __forceinline__ void load_window(u64 atw) {
+        wbase = atw;
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
+        u8 *wb = (u8 *)win;
         for (int j = 0; j < KD_WIN / 64; j++) {
-            const u64 a = at + (u64)j * 64u + (u64)lane_id();
-            win[j * 64 + lane_id()] = (a < nbytes) ? in[a] : (u8)0;
+            const u64 a = atw * 4u + (u64)j * 64u + (u64)lane_id();
+            wb[j * 64 + lane_id()] = (a < nbytes) ? in[a] : (u8)0;
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
     }
-    __device__ __forceinline__ void fill() {
-        while (bc <= 56) {
-            if (pos >= wbase + KD_WIN) load_window(pos);
-            bb |= (u64)win[pos - wbase] << (56 - bc);
-            bc += 8;
-            pos++;
+    __device__ __forceinline__ void fill() { // at least 33 valid bits afterwards
+        if (bc <= 32) {
+            if (wpos >= wbase + KD_WIN / 4) load_window(wpos);
+            const u32 w = __builtin_bswap32(win[wpos - wbase]);
+            bb |= (u64)w << (32 - bc);
+            bc += 32;
+            wpos++;
         }
+    }
+    __device__ __forceinline__ void start(u64 bit) {
+        bb = 0; bc = 0;
+        wpos = bit >> 5;
+        load_window(wpos);
+        fill();
+        skip((int)(bit & 31u));
     }
     __device__ __forceinline__ u32 peek(int k) { return k ? (u32)(bb >> (64 - k)) : 0u; }
     __device__ __forceinline__ void skip(int k) { bb = (k >= 64) ? 0ull : (bb << k); bc -= k; }
     __device__ __forceinline__ u32 bits(int k) { fill(); u32 v = peek(k); skip(k); return v; }
-    __device__ __forceinline__ u64 consumed() const { return pos * 8u - (u64)bc; }
+    __device__ __forceinline__ u64 consumed() const { return wpos * 32u - (u64)bc; }
     // the reference fails when it needs a byte that is not there: a consumed bit past the end
     __device__ __forceinline__ bool over() const { return consumed() > nbytes * 8u; }
 };
+
+#define KD_LUT_BITS 10
 
 __global__ __launch_bounds__(64) void kd_huff(const u8 *__restrict__ in, u64 nbytes,
                                               const u64 *__restrict__ cand, u32 block_size, u32 S,
                                               u8 *__restrict__ bwt, u32 *__restrict__ meta) {
     const u32 b = blockIdx.x;
     const int lane = lane_id();
-    __shared__ u8 win[KD_WIN];
+    __shared__ u32 win[KD_WIN / 4];
+    __shared__ u16 lut[6][1 << KD_LUT_BITS]; // next 10 bits -> (symbol << 5) | length; 0 = walk the limits
     __shared__ u8 sel[SEL_MAX + 2];
     __shared__ u8 lens[6][MAX_ALPHA + 2];
     __shared__ int limits[6][KD_MAXLEN + 1];
     __shared__ int bases[6][KD_MAXLEN + 2];
     __shared__ u16 symbols[6][MAX_ALPHA + 2];
     __shared__ int minlen[6];
-    __shared__ u8 symmap[256];
+    __shared__ __attribute__((aligned(16))) u8 symmap[256];
     __shared__ u8 tmtf[256];
     u32 *mt = meta + (size_t)b * KM_WORDS;
     u8 *out = bwt + (size_t)b * S;
 
     KdBits br;
-    br.in = in; br.nbytes = nbytes; br.win = win; br.bb = 0; br.bc = 0;
-    const u64 startbit = cand[b] + 48u;
-    br.pos = startbit >> 3;
-    br.load_window(br.pos);
-    if (startbit & 7u) (void)br.bits((int)(startbit & 7u));
+    br.in = in; br.nbytes = nbytes; br.win = win;
+    br.start(cand[b] + 48u);
 
     u32 status = KS_OK, len = 0, orig = 0, crc = 0;
     // zeroed tables: a selector may name a table the block does not define (the reference's arrays
@@ -174,7 +185,7 @@ __global__ __launch_bounds__(64) void kd_huff(const u8 *__restrict__ in, u64 nby
             int u = 0;
             for (;;) {
                 br.fill();
-                // leading ones of the buffer (at least 57 valid bits)
+                // leading ones of the buffer (at least 33 valid bits)
                 const int ones = (~br.bb) ? __clzll((long long)~br.bb) : 64;
                 if (ones < br.bc) { u += ones; br.skip(ones + 1); break; }
                 u += br.bc;
@@ -236,32 +247,60 @@ __global__ __launch_bounds__(64) void kd_huff(const u8 *__restrict__ in, u64 nby
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
-        // symbols -> BWT bytes, S/BZip2BlockDecompressor.swift:266-321
-        u32 L = (u32)lane * 4u;
-        L = L | ((L + 1) << 8) | ((L + 2) << 16) | ((L + 3) << 24);
-        u32 rep = 0, inc = 1, mtfv = 0;
-        int gpos = -1, gidx = -1, cur = sel[0];
+        // the reference's search (S/BZip2HuffmanStageDecoder.swift:164-176), run once for every
+        // 10-bit pattern: what it finds within 10 bits goes into a table, the rest walks the limits
+        for (int t = 0; t < 6; t++) {
+            for (int x = lane; x < (1 << KD_LUT_BITS); x += 64) {
+                u32 e = 0;
+                for (int cl = minlen[t]; cl <= KD_LUT_BITS; cl++) {
+                    if (cl == 0) break; // a table the block does not define: walk
+                    const int code = x >> (KD_LUT_BITS - cl);
+                    if (code <= limits[t][cl]) {
+                        const int ix = code - bases[t][cl];
+                        const u32 sy = (ix >= 0 && ix < MAX_ALPHA) ? symbols[t][ix] : 511u; // 511: no symbol
+                        e = (sy << 5) | (u32)cl;
+                        break;
+                    }
+                }
+                lut[t][x] = (u16)e;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        // symbols -> BWT bytes, S/BZip2BlockDecompressor.swift:266-321.  The MTF list holds the
+        // bytes themselves (the symbol map applied to the identity list), 4 per lane.
+        u32 L = ((const u32 *)symmap)[lane];
+        u32 rep = 0, inc = 1, curbyte = symmap[0];
+        int gleft = 0, gidx = -1, cur = sel[0];
         for (;;) {
-            gpos++;
-            if (gpos % GROUP == 0) {
+            if (gleft == 0) {
+                gleft = GROUP;
                 gidx++;
                 if (gidx == nsel) { status = KS_DECODE; break; }
                 cur = sel[gidx];
                 if (cur >= 6) { status = KS_DECODE; break; }
             }
+            gleft--;
             br.fill();
-            int cl = minlen[cur];
             int sym = -1;
-            while (cl <= KD_MAXLEN) {
-                const int code = (int)br.peek(cl);
-                if (code <= limits[cur][cl]) {
-                    const int ix = code - bases[cur][cl];
-                    if (ix >= 0 && ix < MAX_ALPHA) sym = symbols[cur][ix];
-                    break;
+            const u32 e = lut[cur][br.peek(KD_LUT_BITS)];
+            if (e) {
+                br.skip((int)(e & 31u));
+                sym = (int)(e >> 5);
+                if (sym == 511) sym = -1;
+            } else {
+                int cl = minlen[cur];
+                while (cl <= KD_MAXLEN) {
+                    const int code = (int)br.peek(cl);
+                    if (code <= limits[cur][cl]) {
+                        const int ix = code - bases[cur][cl];
+                        if (ix >= 0 && ix < MAX_ALPHA) sym = symbols[cur][ix];
+                        break;
+                    }
+                    cl++;
                 }
-                cl++;
+                br.skip(min(cl, KD_MAXLEN + 1));
             }
-            br.skip(min(cl, KD_MAXLEN + 1));
             if (br.over()) { status = KS_INSUFFICIENT; break; }
             if (sym < 0) { status = KS_DECODE; break; }
             if (sym == 0) {
@@ -273,16 +312,15 @@ __global__ __launch_bounds__(64) void kd_huff(const u8 *__restrict__ in, u64 nby
             } else {
                 if (rep > 0) {
                     if (len + rep > block_size) { status = KS_BLOCK_SIZE; break; }
-                    const u8 byte = symmap[mtfv];
-                    for (u32 q = lane; q < rep; q += 64) out[len + q] = byte;
+                    for (u32 q = lane; q < rep; q += 64) out[len + q] = (u8)curbyte;
                     len += rep;
                     rep = 0;
                     inc = 1;
                 }
                 if (sym == eob) break;
                 if (len >= block_size) { status = KS_BLOCK_SIZE; break; }
-                mtfv = kd_index_to_front(L, (u32)(sym - 1) & 255u);
-                out[len++] = symmap[mtfv];
+                curbyte = kd_index_to_front(L, (u32)(sym - 1) & 255u);
+                out[len++] = (u8)curbyte;
             }
             if (rep > 2u * 900000u + 2u) { status = KS_BLOCK_SIZE; break; }
         }
