@@ -603,6 +603,9 @@ bool host_bits(const std::vector<u8> &buf, u64 buf_bit0, u64 nbits_total, u64 bi
 
 // Decodes the stream at d_in into d_out.  Returns BZ2HIP_OK or the first error the reference would
 // have thrown; *produced = bytes it would have handed out before that (written to d_out).
+// Candidates are decoded KD_BATCH at a time (bounded workspace); the chain walk continues across
+// batches.
+#define KD_BATCH 1024
 int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size_t cap, size_t *produced,
                    u32 *blocks_out) {
     *produced = 0;
@@ -623,8 +626,8 @@ int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size
     const u32 S = ((block_size + 64 + RTILE - 1) / RTILE) * RTILE;
 
     DevBuf D;
-    // candidates: a block is at least ~ 80 bits long; the scan keeps what fits and reports overflow
-    const u32 cand_cap = (u32)std::min<u64>(nbytes / 8 + 16, 1u << 22);
+    // a block is at least ~ 130 bits long: the scan cannot find more real blocks than this
+    const u32 cand_cap = (u32)std::min<u64>(nbytes / 8 + 16, 1u << 24);
     u64 *d_cand = D.get<u64>(cand_cap);
     u32 *d_ncand = D.get<u32>(4);
     HIPCHK(hipMemsetAsync(d_ncand, 0, 16, st));
@@ -641,165 +644,171 @@ int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size
         std::sort(cand.begin(), cand.end());
         HIPCHK(hipMemcpyAsync(d_cand, cand.data(), ncand * sizeof(u64), hipMemcpyHostToDevice, st));
     }
-    // the tail of the stream on the host (end marker + stored CRC are read there)
-    std::vector<u32> meta((size_t)ncand * KM_WORDS);
-    u8 *d_bwt = D.get<u8>((size_t)std::max(ncand, 1u) * S);
-    if (ncand) {
-        u32 *d_meta = D.get<u32>((size_t)ncand * KM_WORDS);
-        kd_huff<<<ncand, 64, 0, st>>>(d_in, nbytes, d_cand, block_size, S, d_bwt, d_meta);
-        KCHECK();
-        HIPCHK(hipMemcpyAsync(meta.data(), d_meta, meta.size() * sizeof(u32), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-    }
-    // chain walk, S/BZip2InputStream.swift:201-242
-    std::vector<u32> chain;   // candidate index of block k
-    int rc = BZ2HIP_OK;       // error that ends the stream after the chain's blocks
-    const char *msg = "";
-    bool have_trailer = false;
-    u32 stored_stream_crc = 0;
+    // batch workspace
+    const u32 NB = std::max(1u, std::min<u32>(ncand, KD_BATCH));
+    const u32 RS = (block_size + KD_RULER - 1) / KD_RULER + 2;
+    u8 *d_bwt = D.get<u8>((size_t)NB * S), *d_tt = D.get<u8>((size_t)NB * S);
+    u32 *d_meta = D.get<u32>((size_t)NB * KM_WORDS);
+    u32 *d_slot = D.get<u32>(NB), *d_n = D.get<u32>(NB), *d_orig = D.get<u32>(NB);
+    u32 *d_base = D.get<u32>((size_t)NB * 256);
+    u32 *d_merged = D.get<u32>((size_t)NB * S);
+    uint2 *d_rinfo = D.get<uint2>((size_t)NB * RS), *d_visits = D.get<uint2>((size_t)NB * RS);
+    u32 *d_nvis = D.get<u32>(NB), *d_cyc = D.get<u32>(NB);
+    u32 *d_outlen = D.get<u32>(NB), *d_flags = D.get<u32>(NB), *d_outbase = D.get<u32>(NB + 1);
+    u32 *d_crc = D.get<u32>(NB);
+    u32 *d_cagg = nullptr;
+    size_t cagg_cap = 0;
+    std::vector<u32> meta((size_t)NB * KM_WORDS);
+
+    u32 stream_crc = 0, nblocks = 0;
+    size_t out_total = 0;
     u64 cur = 32;
     for (;;) {
         auto it = std::lower_bound(cand.begin(), cand.end(), cur);
-        if (it != cand.end() && *it == cur) {
-            const u32 ci = (u32)(it - cand.begin());
+        if (it == cand.end() || *it != cur) break; // not a block: end marker or garbage, below
+        const u32 i0 = (u32)(it - cand.begin());
+        const u32 nbatch = std::min<u32>(ncand - i0, NB);
+        kd_huff<<<nbatch, 64, 0, st>>>(d_in, nbytes, d_cand + i0, block_size, S, d_bwt, d_meta);
+        KCHECK();
+        HIPCHK(hipMemcpyAsync(meta.data(), d_meta, (size_t)nbatch * KM_WORDS * sizeof(u32),
+                              hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        // chain walk inside the batch, S/BZip2InputStream.swift:201-242
+        std::vector<u32> chain; // batch slot of block k
+        int rc_huff = BZ2HIP_OK;
+        for (;;) {
+            auto jt = std::lower_bound(cand.begin() + i0, cand.begin() + i0 + nbatch, cur);
+            if (jt == cand.begin() + i0 + nbatch || *jt != cur) break;
+            const u32 ci = (u32)(jt - cand.begin()) - i0;
             const u32 *mt = &meta[(size_t)ci * KM_WORDS];
-            if (mt[KM_STATUS] != KS_OK) {
-                rc = map_status(mt[KM_STATUS]);
-                msg = "block could not be decoded";
-                break;
-            }
+            if (mt[KM_STATUS] != KS_OK) { rc_huff = map_status(mt[KM_STATUS]); break; }
             chain.push_back(ci);
             cur = (u64)mt[KM_END_LO] | ((u64)mt[KM_END_HI] << 32);
-            continue;
         }
-        // not a block: end marker or garbage
-        std::vector<u8> tail(16, 0);
-        const u64 byte0 = cur >> 3;
-        const size_t avail = byte0 < nbytes ? std::min<size_t>(16, nbytes - byte0) : 0;
-        if (avail) {
-            HIPCHK(hipMemcpyAsync(tail.data(), d_in + byte0, avail, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-        }
-        tail.resize(avail);
-        u32 m1 = 0, m2 = 0;
-        if (!host_bits(tail, byte0 * 8, total_bits, cur, 24, &m1) ||
-            !host_bits(tail, byte0 * 8, total_bits, cur + 24, 24, &m2)) {
-            rc = BZ2HIP_E_INSUFFICIENT;
-            msg = "Insufficient data";
-        } else if (m1 == 0x177245u && m2 == 0x385090u) {
-            if (!host_bits(tail, byte0 * 8, total_bits, cur + 48, 32, &stored_stream_crc)) {
-                rc = BZ2HIP_E_INSUFFICIENT;
-                msg = "Insufficient data";
-            } else have_trailer = true;
-        } else {
-            rc = BZ2HIP_E_FORMAT;
-            msg = "BZip2 stream format error";
-        }
-        break;
-    }
-    const u32 nb = (u32)chain.size();
-    if (blocks_out) *blocks_out = nb;
-    u32 stream_crc = 0;
-    if (nb) {
-        std::vector<u32> h_slot(nb), h_n(nb), h_orig(nb), h_crc(nb);
-        u32 maxn = 0;
-        u32 first_bad_ptr = nb; // S/BZip2BlockDecompressor.swift:332-334
-        for (u32 k = 0; k < nb; k++) {
-            const u32 *mt = &meta[(size_t)chain[k] * KM_WORDS];
-            h_slot[k] = chain[k];
-            h_n[k] = mt[KM_N];
-            h_orig[k] = mt[KM_ORIG];
-            h_crc[k] = mt[KM_CRC];
-            if (h_orig[k] >= h_n[k] && first_bad_ptr == nb) first_bad_ptr = k;
-            if (h_orig[k] >= h_n[k]) { h_n[k] = 0; h_orig[k] = 0; }
-            maxn = std::max(maxn, h_n[k]);
-        }
-        const u32 RS = (maxn + KD_RULER - 1) / KD_RULER + 2;
-        u32 *d_slot = D.get<u32>(nb), *d_n = D.get<u32>(nb), *d_orig = D.get<u32>(nb);
-        u32 *d_base = D.get<u32>((size_t)nb * 256);
-        u32 *d_merged = D.get<u32>((size_t)nb * S);
-        u8 *d_tt = D.get<u8>((size_t)nb * S);
-        uint2 *d_rinfo = D.get<uint2>((size_t)nb * RS), *d_visits = D.get<uint2>((size_t)nb * RS);
-        u32 *d_nvis = D.get<u32>(nb), *d_cyc = D.get<u32>(nb);
-        u32 *d_outlen = D.get<u32>(nb), *d_flags = D.get<u32>(nb), *d_outbase = D.get<u32>(nb + 1);
-        HIPCHK(hipMemcpyAsync(d_slot, h_slot.data(), nb * 4, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(d_n, h_n.data(), nb * 4, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(d_orig, h_orig.data(), nb * 4, hipMemcpyHostToDevice, st));
-        if (maxn) {
-            kd_hist<<<nb, 256, 0, st>>>(d_bwt, d_slot, d_n, S, d_base);
-            KCHECK();
-            kd_merge<<<nb, 64, 0, st>>>(d_bwt, d_slot, d_n, S, d_base, d_merged);
-            KCHECK();
-            const dim3 gr((RS + 255) / 256, nb);
-            kd_walk_a<<<gr, 256, 0, st>>>(d_merged, d_n, d_orig, S, RS, d_rinfo);
-            KCHECK();
-            kd_walk_b<<<(nb + 63) / 64, 64, 0, st>>>(d_n, d_orig, RS, d_rinfo, d_visits, d_nvis, d_cyc, nb);
-            KCHECK();
-            kd_walk_c<<<gr, 256, 0, st>>>(d_merged, d_n, d_orig, S, RS, d_rinfo, d_visits, d_nvis, d_cyc, d_tt);
-            KCHECK();
-            kd_cycfill<<<dim3(64, nb), 256, 0, st>>>(d_n, d_cyc, S, d_tt);
-            KCHECK();
-        }
-        kd_unrle<false><<<nb, 64, 0, st>>>(d_tt, d_n, S, d_outlen, d_flags, nullptr, nullptr);
-        KCHECK();
-        std::vector<u32> h_outlen(nb), h_flags(nb);
-        HIPCHK(hipMemcpyAsync(h_outlen.data(), d_outlen, nb * 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(h_flags.data(), d_flags, nb * 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        // blocks the reference would have handed out: up to the first one it fails on
-        u32 good = nb; // blocks [0, good) are expanded
-        int rc2 = BZ2HIP_OK;
-        const char *msg2 = "";
-        for (u32 k = 0; k < nb; k++) {
-            if (k == first_bad_ptr) { good = k; rc2 = BZ2HIP_E_START_PTR; msg2 = "BZip2 start pointer invalid"; break; }
-            if (h_flags[k] & 1u) { good = k; rc2 = BZ2HIP_E_FORMAT; msg2 = "block ends where a repeat count is due"; break; }
-        }
-        // ... and that fit: the reference stops at the first block whose CRC fails, so a damaged
-        // block that decodes to something huge must not turn into a capacity error of a later one
-        bool cap_hit = false;
-        std::vector<u32> h_base(1, 0);
-        u64 total = 0;
-        u32 maxlen = 0;
-        for (u32 k = 0; k < good; k++) {
-            if (total + h_outlen[k] > cap || total + h_outlen[k] > 0xfffffff0ull || (h_flags[k] & 2u)) {
-                cap_hit = true;
-                good = k;
-                break;
+        const u32 nb = (u32)chain.size();
+        if (nb) {
+            std::vector<u32> h_n(nb), h_orig(nb), h_crc(nb);
+            u32 maxn = 0;
+            u32 first_bad_ptr = nb; // S/BZip2BlockDecompressor.swift:332-334
+            for (u32 k = 0; k < nb; k++) {
+                const u32 *mt = &meta[(size_t)chain[k] * KM_WORDS];
+                h_n[k] = mt[KM_N];
+                h_orig[k] = mt[KM_ORIG];
+                h_crc[k] = mt[KM_CRC];
+                if (h_orig[k] >= h_n[k]) {
+                    if (first_bad_ptr == nb) first_bad_ptr = k;
+                    h_n[k] = 0;
+                    h_orig[k] = 0;
+                }
+                maxn = std::max(maxn, h_n[k]);
             }
-            total += h_outlen[k];
-            maxlen = std::max(maxlen, h_outlen[k]);
-            h_base.push_back((u32)total);
-        }
-        u32 crc_fail = good;
-        if (good) {
-            HIPCHK(hipMemcpyAsync(d_outbase, h_base.data(), (good + 1) * 4, hipMemcpyHostToDevice, st));
-            kd_unrle<true><<<good, 64, 0, st>>>(d_tt, d_n, S, nullptr, nullptr, d_outbase, d_out);
+            HIPCHK(hipMemcpyAsync(d_slot, chain.data(), nb * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(d_n, h_n.data(), nb * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(d_orig, h_orig.data(), nb * 4, hipMemcpyHostToDevice, st));
+            if (maxn) {
+                kd_hist<<<nb, 256, 0, st>>>(d_bwt, d_slot, d_n, S, d_base);
+                KCHECK();
+                kd_merge<<<nb, 64, 0, st>>>(d_bwt, d_slot, d_n, S, d_base, d_merged);
+                KCHECK();
+                const dim3 gr((RS + 255) / 256, nb);
+                kd_walk_a<<<gr, 256, 0, st>>>(d_merged, d_n, d_orig, S, RS, d_rinfo);
+                KCHECK();
+                kd_walk_b<<<(nb + 63) / 64, 64, 0, st>>>(d_n, d_orig, RS, d_rinfo, d_visits, d_nvis, d_cyc, nb);
+                KCHECK();
+                kd_walk_c<<<gr, 256, 0, st>>>(d_merged, d_n, d_orig, S, RS, d_rinfo, d_visits, d_nvis, d_cyc, d_tt);
+                KCHECK();
+                kd_cycfill<<<dim3(64, nb), 256, 0, st>>>(d_n, d_cyc, S, d_tt);
+                KCHECK();
+            }
+            kd_unrle<false><<<nb, 64, 0, st>>>(d_tt, d_n, S, d_outlen, d_flags, nullptr, nullptr);
             KCHECK();
-            const u32 ETPB = (maxlen + 4095) / 4096 + 1;
-            u32 *d_cagg = D.get<u32>((size_t)good * ETPB), *d_crc = D.get<u32>(good);
-            run_crc_blocks(c, d_out, d_outbase, (int)good, maxlen, d_cagg, ETPB, d_crc);
-            std::vector<u32> got(good);
-            HIPCHK(hipMemcpyAsync(got.data(), d_crc, good * 4, hipMemcpyDeviceToHost, st));
+            std::vector<u32> h_outlen(nb), h_flags(nb);
+            HIPCHK(hipMemcpyAsync(h_outlen.data(), d_outlen, nb * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(h_flags.data(), d_flags, nb * 4, hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
+            // blocks the reference would have handed out: up to the first one it fails on ...
+            u32 good = nb; // blocks [0, good) are expanded
+            int rc2 = BZ2HIP_OK;
+            const char *msg2 = "";
+            for (u32 k = 0; k < nb; k++) {
+                if (k == first_bad_ptr) { good = k; rc2 = BZ2HIP_E_START_PTR; msg2 = "BZip2 start pointer invalid"; break; }
+                if (h_flags[k] & 1u) { good = k; rc2 = BZ2HIP_E_FORMAT; msg2 = "block ends where a repeat count is due"; break; }
+            }
+            // ... and that fit: the reference stops at the first block whose CRC fails, so a damaged
+            // block that decodes to something huge must not turn into a capacity error of a later one
+            std::vector<u32> h_base(1, 0);
+            u64 total = 0;
+            u32 maxlen = 0;
             for (u32 k = 0; k < good; k++) {
-                if (got[k] != h_crc[k]) { crc_fail = k; break; }
-                stream_crc = ((stream_crc << 1) | (stream_crc >> 31)) ^ h_crc[k];
+                if (out_total + total + h_outlen[k] > cap || total + h_outlen[k] > 0xfffffff0ull || (h_flags[k] & 2u)) {
+                    good = k;
+                    rc2 = BZ2HIP_E_CAP;
+                    msg2 = "output buffer too small";
+                    break;
+                }
+                total += h_outlen[k];
+                maxlen = std::max(maxlen, h_outlen[k]);
+                h_base.push_back((u32)total);
             }
+            if (good) {
+                u8 *o = d_out + out_total;
+                HIPCHK(hipMemcpyAsync(d_outbase, h_base.data(), (good + 1) * 4, hipMemcpyHostToDevice, st));
+                kd_unrle<true><<<good, 64, 0, st>>>(d_tt, d_n, S, nullptr, nullptr, d_outbase, o);
+                KCHECK();
+                const u32 ETPB = (maxlen + 4095) / 4096 + 1;
+                if ((size_t)good * ETPB > cagg_cap) {
+                    cagg_cap = (size_t)good * ETPB;
+                    d_cagg = D.get<u32>(cagg_cap);
+                }
+                run_crc_blocks(c, o, d_outbase, (int)good, maxlen, d_cagg, ETPB, d_crc);
+                std::vector<u32> got(good);
+                HIPCHK(hipMemcpyAsync(got.data(), d_crc, good * 4, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                for (u32 k = 0; k < good; k++) {
+                    if (got[k] != h_crc[k]) {
+                        // the block's bytes are out before its CRC is compared (S/BZip2InputStream.swift:209-212)
+                        *produced = out_total + h_base[k + 1];
+                        if (blocks_out) *blocks_out = nblocks + k + 1;
+                        c->err = "BZip2 block CRC error";
+                        return BZ2HIP_E_BLOCK_CRC;
+                    }
+                    stream_crc = ((stream_crc << 1) | (stream_crc >> 31)) ^ h_crc[k];
+                }
+            }
+            out_total += (size_t)total;
+            nblocks += good;
+            *produced = out_total;
+            if (blocks_out) *blocks_out = nblocks;
+            if (rc2 != BZ2HIP_OK) { c->err = msg2; return rc2; }
         }
-        if (crc_fail < good) {
-            // the block's bytes are out before its CRC is compared (S/BZip2InputStream.swift:209-212)
-            *produced = h_base[crc_fail + 1];
-            c->err = "BZip2 block CRC error";
-            return BZ2HIP_E_BLOCK_CRC;
+        if (rc_huff != BZ2HIP_OK) { c->err = "block could not be decoded"; return rc_huff; }
+    }
+    // not a block: end marker or garbage
+    std::vector<u8> tail(16, 0);
+    const u64 byte0 = cur >> 3;
+    const size_t avail = byte0 < nbytes ? std::min<size_t>(16, nbytes - byte0) : 0;
+    if (avail) {
+        HIPCHK(hipMemcpyAsync(tail.data(), d_in + byte0, avail, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    tail.resize(avail);
+    u32 m1 = 0, m2 = 0, stored = 0;
+    if (!host_bits(tail, byte0 * 8, total_bits, cur, 24, &m1) ||
+        !host_bits(tail, byte0 * 8, total_bits, cur + 24, 24, &m2)) {
+        c->err = "Insufficient data";
+        return BZ2HIP_E_INSUFFICIENT;
+    }
+    if (m1 == 0x177245u && m2 == 0x385090u) {
+        if (!host_bits(tail, byte0 * 8, total_bits, cur + 48, 32, &stored)) {
+            c->err = "Insufficient data";
+            return BZ2HIP_E_INSUFFICIENT;
         }
-        *produced = (size_t)total;
-        if (cap_hit) { c->err = "output buffer too small"; return BZ2HIP_E_CAP; }
-        if (rc2 != BZ2HIP_OK) { c->err = msg2; return rc2; }
+        if (stored != stream_crc) {
+            c->err = "BZip2 stream CRC error";
+            return BZ2HIP_E_STREAM_CRC;
+        }
+        return BZ2HIP_OK;
     }
-    if (rc != BZ2HIP_OK) { c->err = msg; return rc; }
-    if (have_trailer && stored_stream_crc != stream_crc) {
-        c->err = "BZip2 stream CRC error";
-        return BZ2HIP_E_STREAM_CRC;
-    }
-    return BZ2HIP_OK;
+    c->err = "BZip2 stream format error";
+    return BZ2HIP_E_FORMAT;
 }

@@ -61,6 +61,23 @@ def test_large_roundtrip(ctx):
     assert rc == -4 and len(out) > 0 and out == data[:len(out)]
 
 
+def test_more_blocks_than_one_batch(ctx):
+    # > 1024 blocks: the chain walk continues across candidate batches
+    data = corpus.mixed(160, 77).tobytes()
+    stream = ctx.compress(data, 1)
+    rc, out = ctx.decompress(stream, len(data))
+    assert rc == 0 and out == data
+    assert ctx.last_stats()["blocks"] > 1024
+    bad = bytearray(stream)
+    bad[len(bad) * 3 // 4] ^= 8   # damage in a later batch: the prefix is delivered
+    rc, out = ctx.decompress(bytes(bad), len(data))
+    # (a block whose CRC fails has been handed out too: only what precedes it is the input)
+    a, b = np.frombuffer(out, dtype=np.uint8), np.frombuffer(data, dtype=np.uint8)[:len(out)]
+    diff = np.flatnonzero(a != b[:a.size])
+    first = int(diff[0]) if diff.size else a.size
+    assert rc != 0 and first > len(data) // 2
+
+
 def test_errors_follow_the_oracle(ctx):
     data = corpus.mixed(1, 3).tobytes()[:350000]
     s = bz2.compress(data, 1)
