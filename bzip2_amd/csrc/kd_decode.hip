@@ -5,9 +5,10 @@
 // 84-181) and BZip2BitInputStream (S/BZip2BitInputStream.swift:53-146) for a whole stream resident in
 // HBM.  The reference decodes one block after the other; here every block is decoded at once:
 //   kd_scan_magic : every bit offset is tested for the 48-bit block magic (blocks abut at any bit)
-//   kd_huff       : one wavefront per candidate: header, selectors, code lengths, canonical tables,
-//                   then the serial Huffman / RUNA-RUNB / inverse MTF loop (list 4 entries per lane,
-//                   DPP rotate) -> BWT bytes, origin pointer, stored CRC, end bit
+//   kd_huff       : two wavefronts per candidate: header, selectors, code lengths, canonical tables,
+//                   then wave 0 decodes Huffman symbols into an LDS ring and wave 1 turns them into
+//                   BWT bytes (RUNA-RUNB runs, inverse MTF: list 4 entries per lane, DPP rotate);
+//                   also origin pointer, stored CRC, end bit
 //   host          : walks the chain magic -> end bit -> magic from bit 32; anything a candidate
 //                   that is not on the chain decoded is ignored
 //   kd_hist / kd_merge : stable counting sort of the BWT bytes = the reference's merged pointers
@@ -122,11 +123,20 @@ struct KdBits {
 
 #define KD_LUT_BITS 10
 
-__global__ __launch_bounds__(64) void kd_huff(const u8 *__restrict__ in, u64 nbytes,
-                                              const u64 *__restrict__ cand, u32 block_size, u32 S,
-                                              u8 *__restrict__ bwt, u32 *__restrict__ meta) {
+#define KD_RING 2048        // symbols between the two waves of kd_huff
+#define KD_SPIN_MAX (1 << 22)
+#define KD_SYM_ERR 0x8000u  // ring entry: the producer stopped with status (entry & 0xff)
+
+// Two waves per block.  Wave 0 parses the header and builds the tables, then only decodes Huffman
+// symbols into an LDS ring; wave 1 turns symbols into BWT bytes (runs, inverse MTF).  The two serial
+// chains run on different SIMDs of the CU.  Errors travel through the ring in symbol order, so the
+// first one in the reference's order wins; a wave that gives up raises s_abort for the other.
+__global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nbytes,
+                                               const u64 *__restrict__ cand, u32 block_size, u32 S,
+                                               u8 *__restrict__ bwt, u32 *__restrict__ meta) {
     const u32 b = blockIdx.x;
     const int lane = lane_id();
+    const int wv = wave_id();
     __shared__ u32 win[KD_WIN / 4];
     __shared__ u16 lut[6][1 << KD_LUT_BITS]; // next 10 bits -> (symbol << 5) | length; 0 = walk the limits
     __shared__ u8 sel[SEL_MAX + 2];
@@ -137,202 +147,273 @@ __global__ __launch_bounds__(64) void kd_huff(const u8 *__restrict__ in, u64 nby
     __shared__ int minlen[6];
     __shared__ __attribute__((aligned(16))) u8 symmap[256];
     __shared__ u8 tmtf[256];
+    __shared__ u16 ring[KD_RING];
+    __shared__ u32 s_head, s_tail, s_abort;
+    __shared__ u32 s_status, s_eob, s_nsel, s_orig, s_crc, s_len, s_end_lo, s_end_hi;
     u32 *mt = meta + (size_t)b * KM_WORDS;
     u8 *out = bwt + (size_t)b * S;
 
     KdBits br;
     br.in = in; br.nbytes = nbytes; br.win = win;
-    br.start(cand[b] + 48u);
-
-    u32 status = KS_OK, len = 0, orig = 0, crc = 0;
-    // zeroed tables: a selector may name a table the block does not define (the reference's arrays
-    // are zero-initialised, S/BZip2HuffmanStageDecoder.swift:44-61)
-    for (int q = lane; q < 6 * (KD_MAXLEN + 1); q += 64) (&limits[0][0])[q] = 0;
-    for (int q = lane; q < 6 * (KD_MAXLEN + 2); q += 64) (&bases[0][0])[q] = 0;
-    for (int q = lane; q < 6 * (MAX_ALPHA + 2); q += 64) { (&symbols[0][0])[q] = 0; (&lens[0][0])[q] = 0; }
-    for (int q = lane; q < 256; q += 64) { symmap[q] = 0; tmtf[q] = (u8)q; }
-    if (lane < 6) minlen[lane] = 0;
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-
-    int eob = 0, ntab = 0, nsel = 0;
-    do {
-        // block header, S/BZip2BlockDecompressor.swift:474-477
-        crc = br.bits(16) << 16;
-        crc |= br.bits(16);
-        const u32 randomised = br.bits(1);
-        orig = br.bits(24);
-        if (br.over()) { status = KS_INSUFFICIENT; break; }
-        if (randomised) { status = KS_RANDOMISED; break; }
-        // symbol map, :203-221
-        int nsym = 0;
-        const u32 ranges = br.bits(16);
-        for (int i = 0; i < 16; i++) {
-            if (ranges & (0x8000u >> i)) {
-                const u32 m = br.bits(16);
-                for (int j = 0; j < 16; j++)
-                    if (m & (0x8000u >> j)) symmap[nsym++] = (u8)(i * 16 + j);
-            }
-        }
-        if (br.over()) { status = KS_INSUFFICIENT; break; }
-        eob = nsym + 1;
-        ntab = (int)br.bits(3);
-        nsel = (int)br.bits(15);
-        if (br.over()) { status = KS_INSUFFICIENT; break; }
-        if (ntab < 2 || ntab > 6 || nsel < 1 || nsel > SEL_MAX - 1) { status = KS_TABLES; break; }
-        // selectors: unary, MTF over the table indices, :238-243
-        for (int i = 0; i < nsel && status == KS_OK; i++) {
-            int u = 0;
-            for (;;) {
-                br.fill();
-                // leading ones of the buffer (at least 33 valid bits)
-                const int ones = (~br.bb) ? __clzll((long long)~br.bb) : 64;
-                if (ones < br.bc) { u += ones; br.skip(ones + 1); break; }
-                u += br.bc;
-                br.skip(br.bc);
-                if (br.over()) { status = KS_INSUFFICIENT; break; }
-            }
-            if (status != KS_OK) break;
-            u &= 255;
-            const u8 v = tmtf[u];
-            for (int j = u; j > 0; j--) tmtf[j] = tmtf[j - 1];
-            tmtf[0] = v;
-            sel[i] = v;
-        }
-        if (status != KS_OK) break;
-        if (br.over()) { status = KS_INSUFFICIENT; break; }
-        // delta-coded code lengths, :246-254
-        for (int t = 0; t < ntab && status == KS_OK; t++) {
-            int cur = (int)br.bits(5);
-            for (int i = 0; i <= eob; i++) {
-                for (;;) {
-                    br.fill();
-                    if (!br.peek(1)) { br.skip(1); break; }
-                    cur += (br.peek(2) & 1u) ? -1 : 1;
-                    br.skip(2);
-                    if (br.over()) break;
-                }
-                if (br.over()) { status = KS_INSUFFICIENT; break; }
-                if (cur < 0 || cur > KD_MAXLEN) { status = KS_TABLES; break; }
-                lens[t][i] = (u8)cur;
-            }
-        }
-        if (status != KS_OK) break;
+    br.bb = 0; br.bc = 0; br.wpos = 0; br.wbase = 0;
+    if (threadIdx.x == 0) { s_head = 0; s_tail = 0; s_abort = 0; s_len = 0; s_end_lo = 0; s_end_hi = 0; }
+    if (wv == 0) {
+        br.start(cand[b] + 48u);
+        u32 status = KS_OK, orig = 0, crc = 0;
+        // zeroed tables: a selector may name a table the block does not define (the reference's
+        // arrays are zero-initialised, S/BZip2HuffmanStageDecoder.swift:44-61)
+        for (int q = lane; q < 6 * (KD_MAXLEN + 1); q += 64) (&limits[0][0])[q] = 0;
+        for (int q = lane; q < 6 * (KD_MAXLEN + 2); q += 64) (&bases[0][0])[q] = 0;
+        for (int q = lane; q < 6 * (MAX_ALPHA + 2); q += 64) { (&symbols[0][0])[q] = 0; (&lens[0][0])[q] = 0; }
+        for (int q = lane; q < 256; q += 64) { symmap[q] = 0; tmtf[q] = (u8)q; }
+        if (lane < 6) minlen[lane] = 0;
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
-        // canonical decode tables, S/BZip2HuffmanStageDecoder.swift:84-141
-        const int alpha = eob + 1;
-        for (int t = 0; t < ntab; t++) {
-            int mn = KD_MAXLEN, mx = 0;
-            for (int i = 0; i < alpha; i++) {
-                const int l = lens[t][i];
-                mx = max(mx, l);
-                mn = min(mn, l);
-            }
-            minlen[t] = mn;
-            for (int i = 0; i < alpha; i++) bases[t][lens[t][i] + 1]++;
-            for (int i = 1; i < KD_MAXLEN + 2; i++) bases[t][i] += bases[t][i - 1];
-            int code = 0;
-            for (int i = mn; i <= mx; i++) {
-                const int base = code;
-                code += bases[t][i + 1] - bases[t][i];
-                bases[t][i] = base - bases[t][i];
-                limits[t][i] = code - 1;
-                code <<= 1;
-            }
-            int ci = 0;
-            for (int bl = mn; bl <= mx; bl++)
-                for (int sy = 0; sy < alpha; sy++)
-                    if (lens[t][sy] == bl) symbols[t][ci++] = (u16)sy;
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        // the reference's search (S/BZip2HuffmanStageDecoder.swift:164-176), run once for every
-        // 10-bit pattern: what it finds within 10 bits goes into a table, the rest walks the limits
-        for (int t = 0; t < 6; t++) {
-            for (int x = lane; x < (1 << KD_LUT_BITS); x += 64) {
-                u32 e = 0;
-                for (int cl = minlen[t]; cl <= KD_LUT_BITS; cl++) {
-                    if (cl == 0) break; // a table the block does not define: walk
-                    const int code = x >> (KD_LUT_BITS - cl);
-                    if (code <= limits[t][cl]) {
-                        const int ix = code - bases[t][cl];
-                        const u32 sy = (ix >= 0 && ix < MAX_ALPHA) ? symbols[t][ix] : 511u; // 511: no symbol
-                        e = (sy << 5) | (u32)cl;
-                        break;
-                    }
+        int eob = 0, ntab = 0, nsel = 0;
+        do {
+            // block header, S/BZip2BlockDecompressor.swift:474-477
+            crc = br.bits(16) << 16;
+            crc |= br.bits(16);
+            const u32 randomised = br.bits(1);
+            orig = br.bits(24);
+            if (br.over()) { status = KS_INSUFFICIENT; break; }
+            if (randomised) { status = KS_RANDOMISED; break; }
+            // symbol map, :203-221
+            int nsym = 0;
+            const u32 ranges = br.bits(16);
+            for (int i = 0; i < 16; i++) {
+                if (ranges & (0x8000u >> i)) {
+                    const u32 m = br.bits(16);
+                    for (int j = 0; j < 16; j++)
+                        if (m & (0x8000u >> j)) symmap[nsym++] = (u8)(i * 16 + j);
                 }
-                lut[t][x] = (u16)e;
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        // symbols -> BWT bytes, S/BZip2BlockDecompressor.swift:266-321.  The MTF list holds the
-        // bytes themselves (the symbol map applied to the identity list), 4 per lane.
-        u32 L = ((const u32 *)symmap)[lane];
-        u32 rep = 0, inc = 1, curbyte = symmap[0];
-        int gleft = 0, gidx = -1, cur = sel[0];
-        for (;;) {
-            if (gleft == 0) {
-                gleft = GROUP;
-                gidx++;
-                if (gidx == nsel) { status = KS_DECODE; break; }
-                cur = sel[gidx];
-                if (cur >= 6) { status = KS_DECODE; break; }
-            }
-            gleft--;
-            br.fill();
-            int sym = -1;
-            const u32 e = lut[cur][br.peek(KD_LUT_BITS)];
-            if (e) {
-                br.skip((int)(e & 31u));
-                sym = (int)(e >> 5);
-                if (sym == 511) sym = -1;
-            } else {
-                int cl = minlen[cur];
-                while (cl <= KD_MAXLEN) {
-                    const int code = (int)br.peek(cl);
-                    if (code <= limits[cur][cl]) {
-                        const int ix = code - bases[cur][cl];
-                        if (ix >= 0 && ix < MAX_ALPHA) sym = symbols[cur][ix];
-                        break;
-                    }
-                    cl++;
-                }
-                br.skip(min(cl, KD_MAXLEN + 1));
             }
             if (br.over()) { status = KS_INSUFFICIENT; break; }
-            if (sym < 0) { status = KS_DECODE; break; }
-            if (sym == 0) {
-                rep += inc;
-                inc <<= 1;
-            } else if (sym == 1) {
-                rep += inc << 1;
-                inc <<= 1;
-            } else {
-                if (rep > 0) {
-                    if (len + rep > block_size) { status = KS_BLOCK_SIZE; break; }
-                    for (u32 q = lane; q < rep; q += 64) out[len + q] = (u8)curbyte;
-                    len += rep;
-                    rep = 0;
-                    inc = 1;
+            eob = nsym + 1;
+            ntab = (int)br.bits(3);
+            nsel = (int)br.bits(15);
+            if (br.over()) { status = KS_INSUFFICIENT; break; }
+            if (ntab < 2 || ntab > 6 || nsel < 1 || nsel > SEL_MAX - 1) { status = KS_TABLES; break; }
+            // selectors: unary, MTF over the table indices, :238-243
+            for (int i = 0; i < nsel && status == KS_OK; i++) {
+                int u = 0;
+                for (;;) {
+                    br.fill();
+                    // leading ones of the buffer (at least 33 valid bits)
+                    const int ones = (~br.bb) ? __clzll((long long)~br.bb) : 64;
+                    if (ones < br.bc) { u += ones; br.skip(ones + 1); break; }
+                    u += br.bc;
+                    br.skip(br.bc);
+                    if (br.over()) { status = KS_INSUFFICIENT; break; }
                 }
-                if (sym == eob) break;
-                if (len >= block_size) { status = KS_BLOCK_SIZE; break; }
-                curbyte = kd_index_to_front(L, (u32)(sym - 1) & 255u);
-                out[len++] = (u8)curbyte;
+                if (status != KS_OK) break;
+                u &= 255;
+                const u8 v = tmtf[u];
+                for (int j = u; j > 0; j--) tmtf[j] = tmtf[j - 1];
+                tmtf[0] = v;
+                sel[i] = v;
             }
-            if (rep > 2u * 900000u + 2u) { status = KS_BLOCK_SIZE; break; }
+            if (status != KS_OK) break;
+            if (br.over()) { status = KS_INSUFFICIENT; break; }
+            // delta-coded code lengths, :246-254
+            for (int t = 0; t < ntab && status == KS_OK; t++) {
+                int cur = (int)br.bits(5);
+                for (int i = 0; i <= eob; i++) {
+                    for (;;) {
+                        br.fill();
+                        if (!br.peek(1)) { br.skip(1); break; }
+                        cur += (br.peek(2) & 1u) ? -1 : 1;
+                        br.skip(2);
+                        if (br.over()) break;
+                    }
+                    if (br.over()) { status = KS_INSUFFICIENT; break; }
+                    if (cur < 0 || cur > KD_MAXLEN) { status = KS_TABLES; break; }
+                    lens[t][i] = (u8)cur;
+                }
+            }
+            if (status != KS_OK) break;
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            // canonical decode tables, S/BZip2HuffmanStageDecoder.swift:84-141
+            const int alpha = eob + 1;
+            for (int t = 0; t < ntab; t++) {
+                int mn = KD_MAXLEN, mx = 0;
+                for (int i = 0; i < alpha; i++) {
+                    const int l = lens[t][i];
+                    mx = max(mx, l);
+                    mn = min(mn, l);
+                }
+                minlen[t] = mn;
+                for (int i = 0; i < alpha; i++) bases[t][lens[t][i] + 1]++;
+                for (int i = 1; i < KD_MAXLEN + 2; i++) bases[t][i] += bases[t][i - 1];
+                int code = 0;
+                for (int i = mn; i <= mx; i++) {
+                    const int base = code;
+                    code += bases[t][i + 1] - bases[t][i];
+                    bases[t][i] = base - bases[t][i];
+                    limits[t][i] = code - 1;
+                    code <<= 1;
+                }
+                int ci = 0;
+                for (int bl = mn; bl <= mx; bl++)
+                    for (int sy = 0; sy < alpha; sy++)
+                        if (lens[t][sy] == bl) symbols[t][ci++] = (u16)sy;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            // the reference's search (S/BZip2HuffmanStageDecoder.swift:164-176), run once for every
+            // 10-bit pattern: what it finds within 10 bits goes into a table, the rest walks the limits
+            for (int t = 0; t < 6; t++) {
+                for (int x = lane; x < (1 << KD_LUT_BITS); x += 64) {
+                    u32 e = 0;
+                    for (int cl = minlen[t]; cl <= KD_LUT_BITS; cl++) {
+                        if (cl == 0) break; // a table the block does not define: walk
+                        const int code = x >> (KD_LUT_BITS - cl);
+                        if (code <= limits[t][cl]) {
+                            const int ix = code - bases[t][cl];
+                            const u32 sy = (ix >= 0 && ix < MAX_ALPHA) ? symbols[t][ix] : 511u; // 511: no symbol
+                            e = (sy << 5) | (u32)cl;
+                            break;
+                        }
+                    }
+                    lut[t][x] = (u16)e;
+                }
+            }
+        } while (0);
+        if (lane == 0) { s_status = status; s_eob = (u32)eob; s_nsel = (u32)nsel; s_orig = orig; s_crc = crc; }
+    }
+    __syncthreads();
+    const u32 status0 = s_status;
+    if (status0 == KS_OK) {
+        const int eob = (int)s_eob;
+        if (wv == 0) {
+            // ---- producer: Huffman symbols, S/BZip2HuffmanStageDecoder.swift:149-181
+            const int nsel = (int)s_nsel;
+            u32 head = 0, tail_seen = 0;
+            int gleft = 0, gidx = -1, cur = sel[0];
+            u32 stop = 0; // 0: running, else the final ring entry has been written
+            while (!stop) {
+                u32 entry;
+                if (gleft == 0) {
+                    gleft = GROUP;
+                    gidx++;
+                    if (gidx == nsel) { entry = KD_SYM_ERR | KS_DECODE; stop = 1; goto push; }
+                    cur = sel[gidx];
+                    if (cur >= 6) { entry = KD_SYM_ERR | KS_DECODE; stop = 1; goto push; }
+                }
+                gleft--;
+                {
+                    br.fill();
+                    int sym = -1;
+                    const u32 e = lut[cur][br.peek(KD_LUT_BITS)];
+                    if (e) {
+                        br.skip((int)(e & 31u));
+                        sym = (int)(e >> 5);
+                        if (sym == 511) sym = -1;
+                    } else {
+                        int cl = minlen[cur];
+                        while (cl <= KD_MAXLEN) {
+                            const int code = (int)br.peek(cl);
+                            if (code <= limits[cur][cl]) {
+                                const int ix = code - bases[cur][cl];
+                                if (ix >= 0 && ix < MAX_ALPHA) sym = symbols[cur][ix];
+                                break;
+                            }
+                            cl++;
+                        }
+                        br.skip(min(cl, KD_MAXLEN + 1));
+                    }
+                    if (br.over()) { entry = KD_SYM_ERR | KS_INSUFFICIENT; stop = 1; }
+                    else if (sym < 0) { entry = KD_SYM_ERR | KS_DECODE; stop = 1; }
+                    else {
+                        entry = (u32)sym;
+                        if (sym == eob) stop = 1;
+                    }
+                }
+            push:
+                if (head - tail_seen >= KD_RING) {
+                    // ring full: wait for the consumer (or for its abort)
+                    u32 spins = 0;
+                    for (;;) {
+                        tail_seen = __hip_atomic_load(&s_tail, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (head - tail_seen < KD_RING) break;
+                        if (__hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ||
+                            ++spins > KD_SPIN_MAX) { stop = 2; break; }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    if (stop == 2) break;
+                }
+                ring[head % KD_RING] = (u16)entry;
+                head++;
+                if ((head & 15u) == 0 || stop)
+                    __hip_atomic_store(&s_head, head, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (lane == 0) {
+                const u64 e = br.consumed();
+                s_end_lo = (u32)e;
+                s_end_hi = (u32)(e >> 32);
+            }
+        } else {
+            // ---- consumer: symbols -> BWT bytes, S/BZip2BlockDecompressor.swift:266-321.  The MTF
+            // list holds the bytes themselves (the symbol map applied to the identity list).
+            u32 L = ((const u32 *)symmap)[lane];
+            u32 rep = 0, inc = 1, curbyte = symmap[0], len = 0;
+            u32 tail = 0, status = KS_OK;
+            bool done = false;
+            while (!done) {
+                // wait for symbols
+                u32 head, spins = 0;
+                for (;;) {
+                    head = __hip_atomic_load(&s_head, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (head != tail) break;
+                    if (++spins > KD_SPIN_MAX) { status = KS_DECODE; done = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (done) break;
+                const u32 avail = min(head - tail, 64u);
+                const u32 mine = ((u32)lane < avail) ? ring[(tail + lane) % KD_RING] : 0u;
+                for (u32 q = 0; q < avail && !done; q++) {
+                    const u32 sym = __builtin_amdgcn_readlane(mine, (int)q);
+                    if (sym & KD_SYM_ERR) { status = sym & 0xffu; done = true; break; }
+                    if (sym == 0) {
+                        rep += inc;
+                        inc <<= 1;
+                    } else if (sym == 1) {
+                        rep += inc << 1;
+                        inc <<= 1;
+                    } else {
+                        if (rep > 0) {
+                            if (len + rep > block_size) { status = KS_BLOCK_SIZE; done = true; break; }
+                            for (u32 k = lane; k < rep; k += 64) out[len + k] = (u8)curbyte;
+                            len += rep;
+                            rep = 0;
+                            inc = 1;
+                        }
+                        if ((int)sym == eob) { done = true; break; }
+                        if (len >= block_size) { status = KS_BLOCK_SIZE; done = true; break; }
+                        curbyte = kd_index_to_front(L, (sym - 1u) & 255u);
+                        out[len++] = (u8)curbyte;
+                    }
+                    if (rep > 2u * 900000u + 2u) { status = KS_BLOCK_SIZE; done = true; break; }
+                }
+                tail += avail;
+                __hip_atomic_store(&s_tail, tail, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (lane == 0) {
+                s_len = len;
+                s_status = status;
+                __hip_atomic_store(&s_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
-    } while (0);
-    if (lane == 0) {
-        const u64 e = br.consumed();
-        mt[KM_STATUS] = status;
-        mt[KM_N] = len;
-        mt[KM_ORIG] = orig;
-        mt[KM_CRC] = crc;
-        mt[KM_END_LO] = (u32)e;
-        mt[KM_END_HI] = (u32)(e >> 32);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mt[KM_STATUS] = s_status;
+        mt[KM_N] = s_len;
+        mt[KM_ORIG] = s_orig;
+        mt[KM_CRC] = s_crc;
+        mt[KM_END_LO] = s_end_lo;
+        mt[KM_END_HI] = s_end_hi;
     }
 }
 
@@ -668,7 +749,7 @@ int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size
         if (it == cand.end() || *it != cur) break; // not a block: end marker or garbage, below
         const u32 i0 = (u32)(it - cand.begin());
         const u32 nbatch = std::min<u32>(ncand - i0, NB);
-        kd_huff<<<nbatch, 64, 0, st>>>(d_in, nbytes, d_cand + i0, block_size, S, d_bwt, d_meta);
+        kd_huff<<<nbatch, 128, 0, st>>>(d_in, nbytes, d_cand + i0, block_size, S, d_bwt, d_meta);
         KCHECK();
         HIPCHK(hipMemcpyAsync(meta.data(), d_meta, (size_t)nbatch * KM_WORDS * sizeof(u32),
                               hipMemcpyDeviceToHost, st));
