@@ -290,6 +290,7 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
             // ---- producer: Huffman symbols, S/BZip2HuffmanStageDecoder.swift:149-181
             const int nsel = (int)s_nsel;
             u32 head = 0, tail_seen = 0;
+            const u64 wsafe = nbytes / 4u;
             int gleft = 0, gidx = -1, cur = sel[0];
             u32 stop = 0; // 0: running, else the final ring entry has been written
             while (!stop) {
@@ -323,7 +324,8 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                         }
                         br.skip(min(cl, KD_MAXLEN + 1));
                     }
-                    if (br.over()) { entry = KD_SYM_ERR | KS_INSUFFICIENT; stop = 1; }
+                    // (no bit past the end can have been used while wpos * 32 <= the stream's bits)
+                    if (br.wpos > wsafe && br.over()) { entry = KD_SYM_ERR | KS_INSUFFICIENT; stop = 1; }
                     else if (sym < 0) { entry = KD_SYM_ERR | KS_DECODE; stop = 1; }
                     else {
                         entry = (u32)sym;
