@@ -100,7 +100,8 @@ struct KdBits {
     __device__ __forceinline__ void fill() { // at least 33 valid bits afterwards
         if (bc <= 32) {
             if (wpos >= wbase + KD_WIN / 4) load_window(wpos);
-            const u32 w = __builtin_bswap32(win[wpos - wbase]);
+            // (readfirstlane: the reader's state is wave-uniform, this keeps it in scalar registers)
+            const u32 w = __builtin_amdgcn_readfirstlane(__builtin_bswap32(win[wpos - wbase]));
             bb |= (u64)w << (32 - bc);
             bc += 32;
             wpos++;
@@ -285,10 +286,10 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
     __syncthreads();
     const u32 status0 = s_status;
     if (status0 == KS_OK) {
-        const int eob = (int)s_eob;
+        const int eob = __builtin_amdgcn_readfirstlane((int)s_eob);
         if (wv == 0) {
             // ---- producer: Huffman symbols, S/BZip2HuffmanStageDecoder.swift:149-181
-            const int nsel = (int)s_nsel;
+            const int nsel = __builtin_amdgcn_readfirstlane((int)s_nsel);
             u32 head = 0, tail_seen = 0;
             const u64 wsafe = nbytes / 4u;
             int gleft = 0, gidx = -1, cur = sel[0];
@@ -299,25 +300,25 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                     gleft = GROUP;
                     gidx++;
                     if (gidx == nsel) { entry = KD_SYM_ERR | KS_DECODE; stop = 1; goto push; }
-                    cur = sel[gidx];
+                    cur = __builtin_amdgcn_readfirstlane((int)sel[gidx]);
                     if (cur >= 6) { entry = KD_SYM_ERR | KS_DECODE; stop = 1; goto push; }
                 }
                 gleft--;
                 {
                     br.fill();
                     int sym = -1;
-                    const u32 e = lut[cur][br.peek(KD_LUT_BITS)];
+                    const u32 e = __builtin_amdgcn_readfirstlane((u32)lut[cur][br.peek(KD_LUT_BITS)]);
                     if (e) {
                         br.skip((int)(e & 31u));
                         sym = (int)(e >> 5);
                         if (sym == 511) sym = -1;
                     } else {
-                        int cl = minlen[cur];
+                        int cl = __builtin_amdgcn_readfirstlane(minlen[cur]);
                         while (cl <= KD_MAXLEN) {
                             const int code = (int)br.peek(cl);
-                            if (code <= limits[cur][cl]) {
-                                const int ix = code - bases[cur][cl];
-                                if (ix >= 0 && ix < MAX_ALPHA) sym = symbols[cur][ix];
+                            if (code <= __builtin_amdgcn_readfirstlane(limits[cur][cl])) {
+                                const int ix = code - __builtin_amdgcn_readfirstlane(bases[cur][cl]);
+                                if (ix >= 0 && ix < MAX_ALPHA) sym = __builtin_amdgcn_readfirstlane((int)symbols[cur][ix]);
                                 break;
                             }
                             cl++;
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                     // ring full: wait for the consumer (or for its abort)
                     u32 spins = 0;
                     for (;;) {
-                        tail_seen = __hip_atomic_load(&s_tail, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        tail_seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_tail, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
                         if (head - tail_seen < KD_RING) break;
                         if (__hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ||
                             ++spins > KD_SPIN_MAX) { stop = 2; break; }
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                 // wait for symbols
                 u32 head, spins = 0;
                 for (;;) {
-                    head = __hip_atomic_load(&s_head, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    head = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_head, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
                     if (head != tail) break;
                     if (++spins > KD_SPIN_MAX) { status = KS_DECODE; done = true; break; }
                     __builtin_amdgcn_s_sleep(1);
