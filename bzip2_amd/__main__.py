@@ -1,0 +1,79 @@
+"""bzip2-like front end over libbz2hip (the reference has no CLI, README.md:10-14).
+
+    python -m bzip2_amd [-1..-9] [-d] [-c] [-k] [-f] [file ...]
+
+Compresses FILE to FILE.bz2 (or decompresses FILE.bz2 to FILE with -d) on GPU 0; with no file or
+with -c it reads stdin / writes stdout.  One stream per file (concatenated streams are not
+continued, as in the reference's decoder).  Needs the built library and a GPU: no CPU fallback."""
+import argparse
+import os
+import sys
+
+from . import Context
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="python -m bzip2_amd", add_help=True)
+    for lv in range(1, 10):
+        ap.add_argument(f"-{lv}", dest="level", action="store_const", const=lv)
+    ap.add_argument("-d", "--decompress", action="store_true")
+    ap.add_argument("-c", "--stdout", action="store_true")
+    ap.add_argument("-k", "--keep", action="store_true")
+    ap.add_argument("-f", "--force", action="store_true")
+    ap.add_argument("files", nargs="*")
+    a = ap.parse_args(argv)
+    level = a.level or 9
+    ctx = Context()
+    rc = 0
+
+    def decode(z):
+        cap = max(len(z) * 6, 1 << 20)
+        while True:
+            code, out = ctx.decompress(z, cap)
+            if code != -4:  # BZ2HIP_E_CAP: a block did not fit
+                return code, out
+            cap *= 4
+
+    try:
+        if not a.files:
+            data = sys.stdin.buffer.read()
+            if a.decompress:
+                code, out = decode(data)
+                sys.stdout.buffer.write(out)
+                if code:
+                    print(f"bzip2_amd: (stdin): error {code}", file=sys.stderr)
+                    rc = 2
+            else:
+                sys.stdout.buffer.write(ctx.compress(data, level))
+            return rc
+        for path in a.files:
+            with open(path, "rb") as f:
+                data = f.read()
+            if a.decompress:
+                code, out = decode(data)
+                if code:
+                    print(f"bzip2_amd: {path}: error {code} after {len(out)} bytes", file=sys.stderr)
+                    rc = 2
+                    continue
+                dst = path[:-4] if path.endswith(".bz2") else path + ".out"
+            else:
+                out = ctx.compress(data, level)
+                dst = path + ".bz2"
+            if a.stdout:
+                sys.stdout.buffer.write(out)
+                continue
+            if os.path.exists(dst) and not a.force:
+                print(f"bzip2_amd: {dst} exists (use -f)", file=sys.stderr)
+                rc = 1
+                continue
+            with open(dst, "wb") as f:
+                f.write(out)
+            if not a.keep:
+                os.remove(path)
+    finally:
+        ctx.close()
+    return rc
+
+
+if __name__ == "__main__":
+    sys.exit(main())

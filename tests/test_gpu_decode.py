@@ -110,3 +110,20 @@ def test_bit_flip_fuzz(ctx):
             continue
         assert rc == MAP[orc_rc], (k, rc, orc_rc)
         assert out == orc_out, k
+
+
+def test_cli_roundtrip(tmp_path):
+    """python -m bzip2_amd: file -> file.bz2 (readable by libbz2) -> file"""
+    import subprocess
+    data = corpus.mixed(2, 4).tobytes()
+    src = tmp_path / "sample.bin"
+    src.write_bytes(data)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    subprocess.check_call([sys.executable, "-m", "bzip2_amd", "-5", "-k", str(src)], env=env, cwd=ROOT)
+    z = (tmp_path / "sample.bin.bz2").read_bytes()
+    assert z[:4] == b"BZh5" and bz2.decompress(z) == data
+    src.unlink()
+    subprocess.check_call([sys.executable, "-m", "bzip2_amd", "-d", str(tmp_path / "sample.bin.bz2")], env=env, cwd=ROOT)
+    assert src.read_bytes() == data and not (tmp_path / "sample.bin.bz2").exists()
+    out = subprocess.run([sys.executable, "-m", "bzip2_amd", "-c"], input=data, capture_output=True, env=env, cwd=ROOT)
+    assert out.returncode == 0 and bz2.decompress(out.stdout) == data
