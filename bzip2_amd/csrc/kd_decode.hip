@@ -63,17 +63,13 @@ __device__ __forceinline__ u32 kd_index_to_front(u32 &L, u32 p) {
     const u32 k = p & 3u;
     const u32 w = __builtin_amdgcn_readlane(L, src);
     const u32 v = (w >> (8u * k)) & 255u;
-    if (p != 0) {
-        u32 up = (u32)__builtin_amdgcn_update_dpp(0, (int)L, 0x138, 0xf, 0xf, false); // wave_shr:1
-        u32 carry = (lane == 0) ? v : (up >> 24);
-        u32 shifted = (L << 8) | carry;
-        if (lane < src) {
-            L = shifted;
-        } else if (lane == src) {
-            u32 keep = (k == 3) ? 0u : (0xffffffffu << (8u * (k + 1u)));
-            L = (shifted & ~keep) | (L & keep);
-        }
-    }
+    // branch-free; for p = 0 the list comes out unchanged
+    const u32 up = (u32)__builtin_amdgcn_update_dpp(0, (int)L, 0x138, 0xf, 0xf, false); // wave_shr:1
+    const u32 carry = (lane == 0) ? v : (up >> 24);
+    const u32 shifted = (L << 8) | carry;
+    const u32 keep = (k == 3) ? 0u : (0xffffffffu << (8u * (k + 1u)));
+    const u32 at_src = (shifted & ~keep) | (L & keep);
+    L = (lane < src) ? shifted : ((lane == src) ? at_src : L);
     return v;
 }
 
@@ -288,31 +284,53 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
     if (status0 == KS_OK) {
         const int eob = __builtin_amdgcn_readfirstlane((int)s_eob);
         if (wv == 0) {
-            // ---- producer: Huffman symbols, S/BZip2HuffmanStageDecoder.swift:149-181
+            // ---- producer: Huffman symbols, S/BZip2HuffmanStageDecoder.swift:149-181.
+            // Every lane looks up the code that would start at bit offset `lane` of the buffer (one
+            // LDS access for the whole window); the true chain of codes is then followed through
+            // those entries with scalar reads, several symbols per window, and the symbols of a
+            // window go to the ring in one store.
             const int nsel = __builtin_amdgcn_readfirstlane((int)s_nsel);
-            u32 head = 0, tail_seen = 0;
-            const u64 wsafe = nbytes / 4u;
+            u32 head = 0, tail_seen = 0, published = 0;
+            const u64 wsafe = nbytes / 4u, nbits = nbytes * 8u;
             int gleft = 0, gidx = -1, cur = sel[0];
-            u32 stop = 0; // 0: running, else the final ring entry has been written
+            u32 stop = 0; // 0: running, 1: the final ring entry is among those being written, 2: gave up
             while (!stop) {
-                u32 entry;
+                u32 mysym = 0, cnt = 0;
                 if (gleft == 0) {
                     gleft = GROUP;
                     gidx++;
-                    if (gidx == nsel) { entry = KD_SYM_ERR | KS_DECODE; stop = 1; goto push; }
-                    cur = __builtin_amdgcn_readfirstlane((int)sel[gidx]);
-                    if (cur >= 6) { entry = KD_SYM_ERR | KS_DECODE; stop = 1; goto push; }
+                    if (gidx == nsel) { mysym = KD_SYM_ERR | KS_DECODE; cnt = 1; stop = 1; }
+                    else {
+                        cur = __builtin_amdgcn_readfirstlane((int)sel[gidx]);
+                        if (cur >= 6) { mysym = KD_SYM_ERR | KS_DECODE; cnt = 1; stop = 1; }
+                    }
                 }
-                gleft--;
-                {
+                if (!stop) {
                     br.fill();
-                    int sym = -1;
-                    const u32 e = __builtin_amdgcn_readfirstlane((u32)lut[cur][br.peek(KD_LUT_BITS)]);
-                    if (e) {
-                        br.skip((int)(e & 31u));
-                        sym = (int)(e >> 5);
-                        if (sym == 511) sym = -1;
-                    } else {
+                    const int usable = min(br.bc - KD_LUT_BITS, 54); // offsets with 10 valid bits
+                    u32 myent = 0;
+                    if (lane <= usable) myent = lut[cur][(u32)((br.bb << lane) >> (64 - KD_LUT_BITS))];
+                    const bool nearend = br.wpos > wsafe;
+                    int off = 0;
+                    while (gleft > 0 && off <= usable) {
+                        const u32 e = __builtin_amdgcn_readlane(myent, off);
+                        if (e == 0) break; // longer than 10 bits (or a table the block does not define)
+                        off += (int)(e & 31u);
+                        gleft--;
+                        u32 entry = e >> 5;
+                        // (no bit past the end can have been used while wpos * 32 <= the stream's bits)
+                        if (nearend && br.wpos * 32u - (u64)(br.bc - off) > nbits) { entry = KD_SYM_ERR | KS_INSUFFICIENT; stop = 1; }
+                        else if (entry == 511u) { entry = KD_SYM_ERR | KS_DECODE; stop = 1; }
+                        else if ((int)entry == eob) stop = 1;
+                        if ((u32)lane == cnt) mysym = entry;
+                        cnt++;
+                        if (stop) break;
+                    }
+                    br.skip(off);
+                    if (cnt == 0) {
+                        // walk the limits for this one symbol
+                        gleft--;
+                        int sym = -1;
                         int cl = __builtin_amdgcn_readfirstlane(minlen[cur]);
                         while (cl <= KD_MAXLEN) {
                             const int code = (int)br.peek(cl);
@@ -324,32 +342,33 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                             cl++;
                         }
                         br.skip(min(cl, KD_MAXLEN + 1));
-                    }
-                    // (no bit past the end can have been used while wpos * 32 <= the stream's bits)
-                    if (br.wpos > wsafe && br.over()) { entry = KD_SYM_ERR | KS_INSUFFICIENT; stop = 1; }
-                    else if (sym < 0) { entry = KD_SYM_ERR | KS_DECODE; stop = 1; }
-                    else {
-                        entry = (u32)sym;
-                        if (sym == eob) stop = 1;
+                        if (nearend && br.over()) { mysym = KD_SYM_ERR | KS_INSUFFICIENT; stop = 1; }
+                        else if (sym < 0) { mysym = KD_SYM_ERR | KS_DECODE; stop = 1; }
+                        else {
+                            mysym = (u32)sym;
+                            if (sym == eob) stop = 1;
+                        }
+                        cnt = 1;
                     }
                 }
-            push:
-                if (head - tail_seen >= KD_RING) {
+                if (head + cnt - tail_seen > KD_RING) {
                     // ring full: wait for the consumer (or for its abort)
                     u32 spins = 0;
                     for (;;) {
                         tail_seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_tail, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
-                        if (head - tail_seen < KD_RING) break;
+                        if (head + cnt - tail_seen <= KD_RING) break;
                         if (__hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ||
                             ++spins > KD_SPIN_MAX) { stop = 2; break; }
                         __builtin_amdgcn_s_sleep(2);
                     }
                     if (stop == 2) break;
                 }
-                ring[head % KD_RING] = (u16)entry;
-                head++;
-                if ((head & 15u) == 0 || stop)
+                if ((u32)lane < cnt) ring[(head + lane) % KD_RING] = (u16)mysym;
+                head += cnt;
+                if (head - published >= 32u || stop) {
+                    published = head;
                     __hip_atomic_store(&s_head, head, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
             if (lane == 0) {
                 const u64 e = br.consumed();
@@ -360,7 +379,7 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
             // ---- consumer: symbols -> BWT bytes, S/BZip2BlockDecompressor.swift:266-321.  The MTF
             // list holds the bytes themselves (the symbol map applied to the identity list).
             u32 L = ((const u32 *)symmap)[lane];
-            u32 rep = 0, inc = 1, curbyte = symmap[0], len = 0;
+            u32 rep = 0, inc = 1, curbyte = symmap[0], len = 0, pend = 0;
             u32 tail = 0, status = KS_OK;
             bool done = false;
             while (!done) {
@@ -377,6 +396,14 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                 const u32 mine = ((u32)lane < avail) ? ring[(tail + lane) % KD_RING] : 0u;
                 for (u32 q = 0; q < avail && !done; q++) {
                     const u32 sym = __builtin_amdgcn_readlane(mine, (int)q);
+                    if (sym >= 2u && sym < KD_SYM_ERR && rep == 0 && (int)sym != eob && len < block_size) {
+                        // the common case: one MTF symbol, no run pending
+                        curbyte = kd_index_to_front(L, (sym - 1u) & 255u);
+                        if ((u32)lane == (len & 63u)) pend = curbyte;
+                        len++;
+                        if ((len & 63u) == 0) out[len - 64u + lane] = (u8)pend;
+                        continue;
+                    }
                     if (sym & KD_SYM_ERR) { status = sym & 0xffu; done = true; break; }
                     if (sym == 0) {
                         rep += inc;
@@ -387,21 +414,29 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                     } else {
                         if (rep > 0) {
                             if (len + rep > block_size) { status = KS_BLOCK_SIZE; done = true; break; }
-                            for (u32 k = lane; k < rep; k += 64) out[len + k] = (u8)curbyte;
-                            len += rep;
-                            rep = 0;
+                            while (rep > 0) {
+                                const u32 lo = len & 63u, take = min(rep, 64u - lo);
+                                if ((u32)lane >= lo && (u32)lane < lo + take) pend = curbyte;
+                                len += take;
+                                rep -= take;
+                                if ((len & 63u) == 0) out[len - 64u + lane] = (u8)pend;
+                            }
                             inc = 1;
                         }
                         if ((int)sym == eob) { done = true; break; }
                         if (len >= block_size) { status = KS_BLOCK_SIZE; done = true; break; }
                         curbyte = kd_index_to_front(L, (sym - 1u) & 255u);
-                        out[len++] = (u8)curbyte;
+                        // bytes gather in a register row (lane = position mod 64): one store per 64
+                        if ((u32)lane == (len & 63u)) pend = curbyte;
+                        len++;
+                        if ((len & 63u) == 0) out[len - 64u + lane] = (u8)pend;
                     }
                     if (rep > 2u * 900000u + 2u) { status = KS_BLOCK_SIZE; done = true; break; }
                 }
                 tail += avail;
                 __hip_atomic_store(&s_tail, tail, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
+            if ((u32)lane < (len & 63u)) out[(len & ~63u) + lane] = (u8)pend; // the last, partial row
             if (lane == 0) {
                 s_len = len;
                 s_status = status;
