@@ -6,11 +6,12 @@
 //
 // MTF is a sequential recurrence over the BWT string.  It is cut into chunks of MTF_CHUNK
 // symbols, one wavefront per chunk, the 256-entry list held 4 entries per lane:
-//   mtf_state   : run the chunk from the identity list -> recency list (distinct symbols by
-//                 last occurrence, latest first) and its length d
+//   mtf_recency : last occurrence of every symbol in the chunk -> recency list (distinct symbols
+//                 by last occurrence, latest first) and its length d
 //   mtf_compose : one wave per block walks the chunks: entry_state(c+1) =
 //                 recency(c) ++ (entry_state(c) minus recency(c))
-//   mtf_replay  : re-run every chunk from its entry state -> MTF position per BWT byte
+//   mtf_replay  : re-run every chunk from its entry state (as last-use times) -> MTF position
+//                 per BWT byte
 // RLE2: zero runs (joined across tiles) become bijective base-2 RUNA/RUNB digits, positions
 // p > 0 become symbol p+1, EOB is appended; output slots by a tile scan.
 #include "ctx.hpp"
@@ -22,31 +23,6 @@ __device__ __forceinline__ u32 identity_list() {
     return l | ((l + 1) << 8) | ((l + 2) << 16) | ((l + 3) << 24);
 }
 
-// One MTF step on the wave-distributed list.  s is wave-uniform.  Returns the position.
-__device__ __forceinline__ u32 mtf_step(u32 &L, u32 s) {
-    const int lane = lane_id();
-    u32 x = L ^ (s * 0x01010101u);
-    u32 z = (x - 0x01010101u) & ~x & 0x80808080u; // lowest flagged byte is an exact zero byte
-    u64 m = __ballot(z != 0);
-    int src = __ffsll((unsigned long long)m) - 1;
-    u32 zz = __builtin_amdgcn_readlane(z, src);
-    u32 k = (u32)(__ffs(zz) - 1) >> 3;
-    u32 pos = (u32)src * 4u + k;
-    if (pos != 0) {
-        // wave_shr:1 (DPP, gfx9): lane l receives lane l-1, lane 0 keeps `old` = 0
-        u32 up = (u32)__builtin_amdgcn_update_dpp(0, (int)L, 0x138, 0xf, 0xf, false);
-        u32 carry = (lane == 0) ? s : (up >> 24);
-        u32 shifted = (L << 8) | carry;
-        if (lane < src) {
-            L = shifted;
-        } else if (lane == src) {
-            u32 keep = (k == 3) ? 0u : (0xffffffffu << (8u * (k + 1u)));
-            L = (shifted & ~keep) | (L & keep);
-        }
-    }
-    return pos;
-}
-
 // byte -> dense symbol map from the present bitmap (java:60-65); smap[256] in LDS
 __device__ __forceinline__ void build_symbol_map(const u32 *__restrict__ presentWords, u8 *smap) {
     if (threadIdx.x < 256) {
@@ -55,68 +31,6 @@ __device__ __forceinline__ void build_symbol_map(const u32 *__restrict__ present
         for (u32 wi = 0; wi < (v >> 5); wi++) cnt += __popc(presentWords[wi]);
         cnt += __popc(presentWords[v >> 5] & ((1u << (v & 31)) - 1u));
         smap[v] = (u8)cnt;
-    }
-}
-
-template <bool REPLAY>
-__global__ __launch_bounds__(256) void k3_mtf_chunks(const u8 *__restrict__ bwt,
-                                                     const u32 *__restrict__ nArr,
-                                                     const u32 *__restrict__ present,
-                                                     u8 *__restrict__ mtfrec,
-                                                     u32 *__restrict__ mtfcnt,
-                                                     u8 *__restrict__ mtfpos, u32 S, u32 CPB) {
-    const u32 b = blockIdx.y;
-    const u32 n = nArr[b];
-    __shared__ u8 smap[256];
-    build_symbol_map(present + b * 8, smap);
-    __syncthreads();
-    const u32 c = blockIdx.x * MTF_WG_CHUNKS + wave_id();
-    const u32 cbase = c * MTF_CHUNK;
-    if (cbase >= n) return;
-    const int lane = lane_id();
-    const u8 *src = bwt + (size_t)b * S;
-    u32 L;
-    if (REPLAY) L = ((const u32 *)(mtfrec + ((size_t)b * CPB + c) * 256))[lane];
-    else L = identity_list();
-    u32 seen = 0;
-    u32 prev = 0xffffffffu;
-    const u32 cend = min(cbase + MTF_CHUNK, n);
-    // the chunk's 16 rows are fetched up front (the slot is padded to whole chunks), so the serial
-    // walk below never waits for memory
-    u8 rowv[MTF_CHUNK / 64];
-#pragma unroll
-    for (int r = 0; r < MTF_CHUNK / 64; r++) rowv[r] = src[cbase + r * 64 + lane];
-#pragma unroll
-    for (int r = 0; r < MTF_CHUNK / 64; r++) {
-        const u32 rowbase = cbase + r * 64;
-        if (rowbase >= cend) break;
-        u32 j = rowbase + lane;
-        u32 sym = (j < cend) ? smap[rowv[r]] : 0;
-        u32 mypos = 0;
-        // only run heads move the list (a repeated symbol is at position 0): visit set bits only
-        u32 left = (u32)__builtin_amdgcn_update_dpp((int)prev, (int)sym, 0x138, 0xf, 0xf, false);
-        u64 heads = __ballot(j < cend && sym != left);
-        while (heads) {
-            const int i = __ffsll((unsigned long long)heads) - 1;
-            heads &= heads - 1;
-            const u32 s = __builtin_amdgcn_readlane(sym, i);
-            const u32 pos = mtf_step(L, s);
-            if (!REPLAY) {
-                if ((s >> 2) == (u32)lane) seen |= 1u << (s & 3);
-            }
-            if (REPLAY) {
-                if (lane == i) mypos = pos;
-            }
-        }
-        prev = __builtin_amdgcn_readlane(sym, 63);
-        if (REPLAY) {
-            if (j < cend) mtfpos[(size_t)b * S + j] = (u8)mypos;
-        }
-    }
-    if (!REPLAY) {
-        ((u32 *)(mtfrec + ((size_t)b * CPB + c) * 256))[lane] = L;
-        u32 d = wave_reduce_add(__popc(seen));
-        if (lane == 0) mtfcnt[(size_t)b * CPB + c] = d;
     }
 }
 

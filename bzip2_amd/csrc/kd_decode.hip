@@ -56,7 +56,8 @@ __global__ __launch_bounds__(256) void kd_scan_magic(const u8 *__restrict__ in, 
 }
 
 // ------------------------------------------------------------------ Huffman + MTF stage
-// inverse of mtf_step (k3_mtf.hip): the symbol at position p goes to the front
+// MoveToFront.indexToFront on the wave-distributed list (4 entries per lane): the entry at
+// position p goes to the front; returns it
 __device__ __forceinline__ u32 kd_index_to_front(u32 &L, u32 p) {
     const int lane = lane_id();
     const int src = (int)(p >> 2);
@@ -632,11 +633,23 @@ __global__ __launch_bounds__(64) void kd_unrle(const u8 *__restrict__ tt, const 
     u32 carry_prev = 256, carry_rs = 0, s_in = 0;
     u32 off = 0;
     bool overflow = false;
-    for (u32 rowbase = 0; rowbase < n; rowbase += 64) {
+    for (u32 rb4 = 0; rb4 < n; rb4 += 256) {
+      // four rows of loads in flight (clamped addresses: the slot is padded), then the rows in turn
+      u32 vq[4], nq[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+          const u32 t = rb4 + r * 64 + lane;
+          vq[r] = p[min(t, S - 1)];
+          nq[r] = p[min(t + 1, S - 1)];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const u32 rowbase = rb4 + r * 64;
+        if (rowbase >= n) break;
         const u32 t = rowbase + lane;
         const bool act = t < n;
-        const u32 v = act ? p[t] : 0u;
-        const u32 nxt = (t + 1 < n) ? p[t + 1] : 256u;
+        const u32 v = act ? vq[r] : 0u;
+        const u32 nxt = (t + 1 < n) ? nq[r] : 256u;
         u32 pv = __shfl_up(v, 1, 64);
         if (lane == 0) pv = carry_prev;
         const bool head = act && (t == 0 || v != pv);
@@ -677,6 +690,7 @@ __global__ __launch_bounds__(64) void kd_unrle(const u8 *__restrict__ tt, const 
         s_in = (__shfl(F, 63, 64) >> s_in) & 1u;
         carry_prev = __shfl(v, 63, 64);
         carry_rs = __shfl(rs, 63, 64);
+      }
     }
     if (!WRITE && lane == 0) {
         outlen[b] = off;
