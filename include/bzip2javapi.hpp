@@ -7,12 +7,15 @@
 //   BZip2BitOutputStream              S/BZip2BitOutputStream.swift:31-128   (host bit cursor)
 //   BZip2BlockCompressor              S/BZip2BlockCompressor.swift:37-321   (GPU at close())
 //   BZip2OutputStream                 S/BZip2OutputStream.swift:31-201      (GPU streaming ABI)
+//   java::io::InputStream             stand-in for JavApi's java.io.InputStream (the source)
+//   BZip2InputStream                  S/BZip2InputStream.swift:45-258       (GPU decoder, whole stream)
 //
 // Header-only; link with -lbz2hip.  No compute happens on the host: the block compressor keeps
 // only the reference's acceptance rule (two counters) to answer write() -> Bool.
 #pragma once
 #include "bz2hip.h"
 
+#include <algorithm>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -31,6 +34,21 @@ struct ByteArrayOutputStream : OutputStream {
     std::vector<uint8_t> buf;
     bool closed = false;
     void write(int b) override { buf.push_back((uint8_t)(b & 0xff)); }
+    void close() override { closed = true; }
+};
+// java.io.InputStream contract used by the reference: read() returns a byte or -1
+// (S/BZip2BitInputStream.swift:60,89,120), close().
+struct InputStream {
+    virtual ~InputStream() {}
+    virtual int read() = 0;
+    virtual void close() {}
+};
+struct ByteArrayInputStream : InputStream {
+    std::vector<uint8_t> buf;
+    size_t pos = 0;
+    bool closed = false;
+    explicit ByteArrayInputStream(std::vector<uint8_t> b) : buf(std::move(b)) {}
+    int read() override { return pos < buf.size() ? (int)buf[pos++] : -1; }
     void close() override { closed = true; }
 };
 }} // namespace java::io
@@ -225,6 +243,92 @@ class BZip2OutputStream : public java::io::OutputStream {
     void close() override {                                                                       // :110-113
         finish();
         outputStream.close();
+    }
+};
+
+// ---- S/BZip2InputStream.swift:45-258 (and BZip2BlockDecompressor, BZip2HuffmanStageDecoder,
+// BZip2BitInputStream under it).  The GPU decodes all blocks of the stream at once, so the source
+// is read to its end at the first read(); after that bytes are served in order, and an error of
+// the stream is thrown where the reference would throw it: after the bytes it would have
+// delivered first (a block's bytes precede its CRC check, :209-212).
+class BZip2InputStream : public java::io::InputStream {
+    java::io::InputStream *inputStream;
+    bool headerless;
+    bool decodedAll = false;
+    std::vector<uint8_t> decoded;
+    size_t pos = 0;
+    int pending = BZ2HIP_OK;
+    std::string pendingText;
+
+    static const char *text(int rc) {
+        switch (rc) {
+        case BZ2HIP_E_INSUFFICIENT: return "Insufficient data";                        // BitInputStream :63
+        case BZ2HIP_E_HEADER: return "Invalid BZip2 header";                           // :177
+        case BZ2HIP_E_FORMAT: return "BZip2 stream format error";                      // :240
+        case BZ2HIP_E_BLOCK_CRC: return "BZip2 block CRC error";                       // BlockDecompressor :456
+        case BZ2HIP_E_STREAM_CRC: return "BZip2 stream CRC error";                     // :233
+        case BZ2HIP_E_TABLES: return "BZip2 block Huffman tables invalid";             // BlockDecompressor :235
+        case BZ2HIP_E_BLOCK_SIZE: return "BZip2 block exceeds declared block size";    // :288,:307
+        case BZ2HIP_E_START_PTR: return "BZip2 start pointer invalid";                 // :333
+        case BZ2HIP_E_DECODE: return "Error decoding BZip2 block";                     // HuffmanStageDecoder :158
+        default: return nullptr;
+        }
+    }
+    void decodeAll() {
+        if (!inputStream) throw BZip2Exception(BZip2Exception::IOException, "Stream closed"); // :157-159
+        decodedAll = true;
+        std::vector<uint8_t> z;
+        if (headerless) { z.push_back('B'); z.push_back('Z'); }                               // :168
+        for (int b; (b = inputStream->read()) >= 0;) z.push_back((uint8_t)b);
+        detail::Ctx ctx;
+        size_t cap = z.size() * 8 + (1u << 20), got = 0;
+        for (;;) { // BZ2HIP_E_CAP: a block did not fit, try again with more room
+            decoded.assign(cap, 0);
+            pending = bz2hip_decompress(ctx.h, z.data(), z.size(), decoded.data(), cap, &got);
+            if (pending != BZ2HIP_E_CAP) break;
+            cap *= 4;
+        }
+        decoded.resize(got);
+        const char *t = text(pending);
+        pendingText = t ? t : std::string("bz2hip: ") + bz2hip_last_error(ctx.h);
+    }
+    void raise() {
+        const int rc = pending;
+        pending = BZ2HIP_OK; // the reference's streamComplete: later reads return -1
+        throw BZip2Exception(rc == BZ2HIP_E_START_PTR ? BZip2Exception::BZip2ExceptionKind
+                                                      : BZip2Exception::IOException, pendingText);
+    }
+
+  public:
+    BZip2InputStream(java::io::InputStream &in, bool headerless_)                              // :250-256
+        : inputStream(&in), headerless(headerless_) {}
+    int read() override {                                                                       // :91-108
+        if (!decodedAll) decodeAll();
+        if (pos < decoded.size()) return decoded[pos++];
+        if (pending != BZ2HIP_OK) raise();
+        return -1;
+    }
+    int read(uint8_t *destination, int offset, int length) {                                    // :113-128
+        if (!decodedAll) decodeAll();
+        if (pos == decoded.size()) {
+            if (pending != BZ2HIP_OK) raise();
+            return -1;
+        }
+        const size_t take = std::min<size_t>((size_t)length, decoded.size() - pos);
+        std::copy(decoded.begin() + pos, decoded.begin() + pos + take, destination + offset);
+        pos += take;
+        return (int)take;
+    }
+    void close() override {                                                                     // :134-147
+        decoded.clear();
+        pos = 0;
+        pending = BZ2HIP_OK;
+        if (inputStream) {
+            java::io::InputStream *s = inputStream;
+            inputStream = nullptr;
+            decodedAll = false;
+            s->close();
+        }
     }
 };
 

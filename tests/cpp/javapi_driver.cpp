@@ -4,6 +4,7 @@
 //   javapi_driver bytewise <level> <in> <out>   BZip2OutputStream.write(int) per byte, finish()
 //   javapi_driver block    <level> <in> <out>   BZip2BlockCompressor + BZip2BitOutputStream, the loop of
 //                                               S/BZip2OutputStream.swift:85-104,131-161 written by hand
+//   javapi_driver decode|decode1 0 <in.bz2> <out>  BZip2InputStream (block reads | byte reads)
 //   javapi_driver errors                        error behaviour; prints one line per check
 #include "../../include/bzip2javapi.hpp"
 
@@ -51,6 +52,37 @@ int main(int argc, char **argv) {
             }
             s.close();
             std::printf("sink closed: %d\n", sink.closed ? 1 : 0);
+            return 0;
+        }
+        if (mode == "decode" || mode == "decode1") {
+            // javapi_driver decode <ignored> <in.bz2> <out>: BZip2InputStream as user code would use it;
+            // an exception is reported after the bytes delivered before it
+            if (argc < 5) return 2;
+            java::io::ByteArrayInputStream src(slurp(argv[3]));
+            BZip2InputStream s(src, false);
+            std::vector<uint8_t> got;
+            try {
+                if (mode == "decode1") {
+                    for (int b; (b = s.read()) >= 0;) got.push_back((uint8_t)b);
+                } else {
+                    uint8_t buf[70000];
+                    for (int k; (k = s.read(buf, 0, (int)sizeof(buf))) >= 0;) got.insert(got.end(), buf, buf + k);
+                }
+                std::printf("ok %zu\n", got.size());
+            } catch (const BZip2Exception &e) {
+                std::printf("%s %s after %zu\n", e.kind == BZip2Exception::IOException ? "IOException" : "BZip2Exception",
+                            e.what(), got.size());
+            }
+            std::printf("after end: %d\n", s.read());
+            s.close();
+            std::printf("source closed: %d\n", src.closed ? 1 : 0);
+            try {
+                s.read();
+                std::printf("read after close: no exception\n");
+            } catch (const BZip2Exception &e) {
+                std::printf("read after close: IOException %s\n", e.what());
+            }
+            spit(argv[4], got);
             return 0;
         }
         if (argc < 5) return 2;

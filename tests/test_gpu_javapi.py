@@ -50,3 +50,39 @@ def test_javapi_errors():
     assert "header bytes at construction: 4" in out
     assert "write after finish: IOException Write beyond end of stream" in out
     assert "sink closed: 1" in out
+
+
+def _decode(mode, stream, tmp_path):
+    fin = tmp_path / "in.bz2"
+    fout = tmp_path / "out.bin"
+    fin.write_bytes(stream)
+    r = subprocess.run([DRIVER, mode, "0", str(fin), str(fout)], check=True, timeout=120, capture_output=True)
+    return r.stdout.decode(), fout.read_bytes()
+
+
+@pytest.mark.parametrize("mode", ["decode", "decode1"])
+def test_javapi_input_stream(orc, tmp_path, mode):
+    """BZip2InputStream (S/BZip2InputStream.swift:45-258) through the C++ mirror"""
+    import bz2
+    d = _data()
+    for stream in (bz2.compress(d, 9), orc.compress(d, 1)[0]):
+        log, out = _decode(mode, stream, tmp_path)
+        assert out == d and f"ok {len(d)}" in log
+        assert "after end: -1" in log and "source closed: 1" in log
+        assert "read after close: IOException Stream closed" in log
+
+
+def test_javapi_input_stream_errors(orc, tmp_path):
+    import bz2
+    d = _data()
+    s = bytearray(bz2.compress(d, 1))
+    bad = bytearray(s); bad[11] ^= 0x10          # stored CRC of the first block
+    log, out = _decode("decode", bytes(bad), tmp_path)
+    rc, want, _ = orc.decompress(bytes(bad), len(d) + 16)
+    assert rc == orc.D_BLOCK_CRC and out == want
+    assert f"IOException BZip2 block CRC error after {len(want)}" in log and "after end: -1" in log
+    log, out = _decode("decode", b"BZh0" + bytes(s[4:]), tmp_path)
+    assert "IOException Invalid BZip2 header after 0" in log
+    log, out = _decode("decode", bytes(s[:len(s) // 2]), tmp_path)
+    rc, want, _ = orc.decompress(bytes(s[:len(s) // 2]), len(d) + 16)
+    assert out == want and "IOException" in log and f"after {len(want)}" in log
