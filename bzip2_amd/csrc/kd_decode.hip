@@ -79,8 +79,8 @@ __device__ __forceinline__ u32 kd_index_to_front(u32 &L, u32 p) {
 struct KdBits {
     const u8 *in;
     u64 nbytes, wpos, wbase; // wpos = next stream word (4 bytes) to enter the buffer; window = [wbase, wbase + KD_WIN/4)
-    u64 bb;                  // bit buffer, MSB first
-    int bc;                  // valid bits in bb
+    u64 hi, lo;              // 128-bit buffer, MSB of hi first
+    int bc;                  // valid bits
     u32 *win;
     __device__ __forceinline__ void load_window(u64 atw) {
         wbase = atw;
@@ -94,25 +94,32 @@ struct KdBits {
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
     }
-    __device__ __forceinline__ void fill() { // at least 33 valid bits afterwards
-        if (bc <= 32) {
+    __device__ __forceinline__ void fill() { // at least 97 valid bits afterwards
+        while (bc <= 96) {
             if (wpos >= wbase + KD_WIN / 4) load_window(wpos);
             // (readfirstlane: the reader's state is wave-uniform, this keeps it in scalar registers)
             const u32 w = __builtin_amdgcn_readfirstlane(__builtin_bswap32(win[wpos - wbase]));
-            bb |= (u64)w << (32 - bc);
+            const unsigned __int128 t = (unsigned __int128)w << (96 - bc);
+            hi |= (u64)(t >> 64);
+            lo |= (u64)t;
             bc += 32;
             wpos++;
         }
     }
     __device__ __forceinline__ void start(u64 bit) {
-        bb = 0; bc = 0;
+        hi = 0; lo = 0; bc = 0;
         wpos = bit >> 5;
         load_window(wpos);
         fill();
         skip((int)(bit & 31u));
     }
-    __device__ __forceinline__ u32 peek(int k) { return k ? (u32)(bb >> (64 - k)) : 0u; }
-    __device__ __forceinline__ void skip(int k) { bb = (k >= 64) ? 0ull : (bb << k); bc -= k; }
+    __device__ __forceinline__ u32 peek(int k) { return k ? (u32)(hi >> (64 - k)) : 0u; } // k <= 32
+    __device__ __forceinline__ void skip(int k) { // k <= 127
+        const unsigned __int128 t = (((unsigned __int128)hi << 64) | lo) << k;
+        hi = (u64)(t >> 64);
+        lo = (u64)t;
+        bc -= k;
+    }
     __device__ __forceinline__ u32 bits(int k) { fill(); u32 v = peek(k); skip(k); return v; }
     __device__ __forceinline__ u64 consumed() const { return wpos * 32u - (u64)bc; }
     // the reference fails when it needs a byte that is not there: a consumed bit past the end
@@ -153,7 +160,7 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
 
     KdBits br;
     br.in = in; br.nbytes = nbytes; br.win = win;
-    br.bb = 0; br.bc = 0; br.wpos = 0; br.wbase = 0;
+    br.hi = 0; br.lo = 0; br.bc = 0; br.wpos = 0; br.wbase = 0;
     if (threadIdx.x == 0) { s_head = 0; s_tail = 0; s_abort = 0; s_len = 0; s_end_lo = 0; s_end_hi = 0; }
     if (wv == 0) {
         br.start(cand[b] + 48u);
@@ -197,11 +204,11 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                 int u = 0;
                 for (;;) {
                     br.fill();
-                    // leading ones of the buffer (at least 33 valid bits)
-                    const int ones = (~br.bb) ? __clzll((long long)~br.bb) : 64;
-                    if (ones < br.bc) { u += ones; br.skip(ones + 1); break; }
-                    u += br.bc;
-                    br.skip(br.bc);
+                    // leading ones of the first 64 bits of the buffer (at least 97 are valid)
+                    const int ones = (~br.hi) ? __clzll((long long)~br.hi) : 64;
+                    if (ones < 64) { u += ones; br.skip(ones + 1); break; }
+                    u += 64;
+                    br.skip(64);
                     if (br.over()) { status = KS_INSUFFICIENT; break; }
                 }
                 if (status != KS_OK) break;
@@ -297,6 +304,8 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
             u32 stop = 0; // 0: running, 1: the final ring entry is among those being written, 2: gave up
             while (!stop) {
                 u32 mysym = 0, cnt = 0;
+                u64 visited = 0;
+                bool fast = false;
                 if (gleft == 0) {
                     gleft = GROUP;
                     gidx++;
@@ -308,24 +317,55 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                 }
                 if (!stop) {
                     br.fill();
-                    const int usable = min(br.bc - KD_LUT_BITS, 54); // offsets with 10 valid bits
-                    u32 myent = 0;
-                    if (lane <= usable) myent = lut[cur][(u32)((br.bb << lane) >> (64 - KD_LUT_BITS))];
+                    const int usable = 63; // every lane's offset has 10 valid bits (97 are buffered)
+                    const u64 fld = lane ? ((br.hi << lane) | (br.lo >> (64 - lane))) : br.hi;
+                    const u32 myent = lut[cur][(u32)(fld >> (64 - KD_LUT_BITS))];
                     const bool nearend = br.wpos > wsafe;
                     int off = 0;
-                    while (gleft > 0 && off <= usable) {
-                        const u32 e = __builtin_amdgcn_readlane(myent, off);
-                        if (e == 0) break; // longer than 10 bits (or a table the block does not define)
-                        off += (int)(e & 31u);
-                        gleft--;
-                        u32 entry = e >> 5;
-                        // (no bit past the end can have been used while wpos * 32 <= the stream's bits)
-                        if (nearend && br.wpos * 32u - (u64)(br.bc - off) > nbits) { entry = KD_SYM_ERR | KS_INSUFFICIENT; stop = 1; }
-                        else if (entry == 511u) { entry = KD_SYM_ERR | KS_DECODE; stop = 1; }
-                        else if ((int)entry == eob) stop = 1;
-                        if ((u32)lane == cnt) mysym = entry;
-                        cnt++;
-                        if (stop) break;
+                    if (!nearend) {
+                        // entries the scalar chain stops at: no entry, no symbol, end of block
+                        const u32 sy = myent >> 5;
+                        const u32 ment = myent | ((myent == 0 || sy == 511u || (int)sy == eob) ? 0x8000u : 0u);
+                        int n = 0;
+                        while (n < gleft && off <= usable) {
+                            const u32 e = __builtin_amdgcn_readlane(ment, off);
+                            if (e & 0x8000u) break;
+                            visited |= 1ull << off;
+                            off += (int)(e & 31u);
+                            n++;
+                        }
+                        if (n > 0) {
+                            // the lanes whose offset the chain visited hold its symbols, in order
+                            fast = true;
+                            gleft -= n;
+                            cnt = (u32)n;
+                            mysym = sy;
+                        } else {
+                            const u32 e = __builtin_amdgcn_readlane(myent, 0);
+                            if (e != 0) { // no symbol for this code, or the end of the block
+                                off = (int)(e & 31u);
+                                gleft--;
+                                mysym = ((e >> 5) == 511u) ? (KD_SYM_ERR | KS_DECODE) : (e >> 5);
+                                cnt = 1;
+                                stop = 1;
+                            }
+                        }
+                    } else {
+                        // the last words of the stream: test every symbol for the end of the data
+                        while (gleft > 0 && off <= usable) {
+                            const u32 e = __builtin_amdgcn_readlane(myent, off);
+                            if (e == 0) break; // longer than 10 bits (or a table the block does not define)
+                            off += (int)(e & 31u);
+                            gleft--;
+                            u32 entry = e >> 5;
+                            // (no bit past the end can have been used while wpos * 32 <= the stream's bits)
+                            if (br.wpos * 32u - (u64)(br.bc - off) > nbits) { entry = KD_SYM_ERR | KS_INSUFFICIENT; stop = 1; }
+                            else if (entry == 511u) { entry = KD_SYM_ERR | KS_DECODE; stop = 1; }
+                            else if ((int)entry == eob) stop = 1;
+                            if ((u32)lane == cnt) mysym = entry;
+                            cnt++;
+                            if (stop) break;
+                        }
                     }
                     br.skip(off);
                     if (cnt == 0) {
@@ -364,7 +404,12 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                     }
                     if (stop == 2) break;
                 }
-                if ((u32)lane < cnt) ring[(head + lane) % KD_RING] = (u16)mysym;
+                if (fast) {
+                    if ((visited >> lane) & 1ull)
+                        ring[(head + (u32)__popcll(visited & ((1ull << lane) - 1ull))) % KD_RING] = (u16)mysym;
+                } else if ((u32)lane < cnt) {
+                    ring[(head + lane) % KD_RING] = (u16)mysym;
+                }
                 head += cnt;
                 if (head - published >= 32u || stop) {
                     published = head;
@@ -395,16 +440,31 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                 if (done) break;
                 const u32 avail = min(head - tail, 64u);
                 const u32 mine = ((u32)lane < avail) ? ring[(tail + lane) % KD_RING] : 0u;
+                // per batch, in the vector domain: which entries are plain MTF symbols, and their list
+                // position split into (lane, byte shift), so that the serial part below is short
+                const u64 plain = __ballot(mine >= 2u && mine < KD_SYM_ERR && (int)mine != eob);
+                const u32 pq = (mine - 1u) & 255u;
+                const u32 pk = (pq >> 2) | ((pq & 3u) << 11); // lane | byte shift << 8
+                bool room = len + avail <= block_size;
                 for (u32 q = 0; q < avail && !done; q++) {
-                    const u32 sym = __builtin_amdgcn_readlane(mine, (int)q);
-                    if (sym >= 2u && sym < KD_SYM_ERR && rep == 0 && (int)sym != eob && len < block_size) {
-                        // the common case: one MTF symbol, no run pending
-                        curbyte = kd_index_to_front(L, (sym - 1u) & 255u);
-                        if ((u32)lane == (len & 63u)) pend = curbyte;
+                    if (((plain >> q) & 1ull) && rep == 0 && room) {
+                        // the common case: one MTF symbol, no run pending (kd_index_to_front inlined)
+                        const u32 k2 = __builtin_amdgcn_readlane(pk, (int)q);
+                        const int src = (int)(k2 & 255u);
+                        const u32 sh = k2 >> 8;
+                        const u32 v = (__builtin_amdgcn_readlane(L, src) >> sh) & 255u;
+                        const u32 up = (u32)__builtin_amdgcn_update_dpp(0, (int)L, 0x138, 0xf, 0xf, false);
+                        const u32 shifted = (L << 8) | ((lane == 0) ? v : (up >> 24));
+                        const u32 m = 0xffffffffu >> (24u - sh); // bytes 0..k of the source lane's word move
+                        const u32 at_src = (shifted & m) | (L & ~m);
+                        L = (lane < src) ? shifted : ((lane == src) ? at_src : L);
+                        curbyte = v;
+                        if ((u32)lane == (len & 63u)) pend = v;
                         len++;
                         if ((len & 63u) == 0) out[len - 64u + lane] = (u8)pend;
                         continue;
                     }
+                    const u32 sym = __builtin_amdgcn_readlane(mine, (int)q);
                     if (sym & KD_SYM_ERR) { status = sym & 0xffu; done = true; break; }
                     if (sym == 0) {
                         rep += inc;
@@ -433,6 +493,7 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                         if ((len & 63u) == 0) out[len - 64u + lane] = (u8)pend;
                     }
                     if (rep > 2u * 900000u + 2u) { status = KS_BLOCK_SIZE; done = true; break; }
+                    room = len + (avail - q) <= block_size; // a run may have been written
                 }
                 tail += avail;
                 __hip_atomic_store(&s_tail, tail, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
