@@ -920,26 +920,26 @@ int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size
             HIPCHK(hipMemcpyAsync(h_outlen.data(), d_outlen, nb * 4, hipMemcpyDeviceToHost, st));
             HIPCHK(hipMemcpyAsync(h_flags.data(), d_flags, nb * 4, hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
-            // blocks the reference would have handed out: up to the first one it fails on ...
+            // blocks the reference would have handed out: up to the first one it fails on, and that
+            // fit (in block order: start pointer, then room for the block's bytes, then its last run).
+            // The reference stops at the first block whose CRC fails, so a damaged block that decodes
+            // to something huge must not turn into a capacity error of a later one: the CRCs of the
+            // blocks before the stop are compared first, below.
             u32 good = nb; // blocks [0, good) are expanded
             int rc2 = BZ2HIP_OK;
             const char *msg2 = "";
-            for (u32 k = 0; k < nb; k++) {
-                if (k == first_bad_ptr) { good = k; rc2 = BZ2HIP_E_START_PTR; msg2 = "BZip2 start pointer invalid"; break; }
-                if (h_flags[k] & 1u) { good = k; rc2 = BZ2HIP_E_FORMAT; msg2 = "block ends where a repeat count is due"; break; }
-            }
-            // ... and that fit: the reference stops at the first block whose CRC fails, so a damaged
-            // block that decodes to something huge must not turn into a capacity error of a later one
             std::vector<u32> h_base(1, 0);
             u64 total = 0;
             u32 maxlen = 0;
-            for (u32 k = 0; k < good; k++) {
+            for (u32 k = 0; k < nb; k++) {
+                if (k == first_bad_ptr) { good = k; rc2 = BZ2HIP_E_START_PTR; msg2 = "BZip2 start pointer invalid"; break; }
                 if (out_total + total + h_outlen[k] > cap || total + h_outlen[k] > 0xfffffff0ull || (h_flags[k] & 2u)) {
                     good = k;
                     rc2 = BZ2HIP_E_CAP;
                     msg2 = "output buffer too small";
                     break;
                 }
+                if (h_flags[k] & 1u) { good = k; rc2 = BZ2HIP_E_FORMAT; msg2 = "block ends where a repeat count is due"; break; }
                 total += h_outlen[k];
                 maxlen = std::max(maxlen, h_outlen[k]);
                 h_base.push_back((u32)total);
