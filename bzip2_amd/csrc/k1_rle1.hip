@@ -172,12 +172,14 @@ struct PrefixArr { // absolute flushed-length prefix = tile-local value + scanne
 
 // first i in (lo, hi] with arr[i] > thr (arr non-decreasing); returns hi+1 if none.  One wave.
 template <typename ARR>
-__device__ u32 wave_search_gt(const ARR arr, u32 lo, u32 hi, u32 thr) {
+__device__ u32 wave_search_gt(const ARR arr, u32 lo, u32 hi, u32 thr, bool top_known = false) {
     const int lane = lane_id();
     if (lo >= hi) return hi + 1;
-    // invariant: answer in (lo, hi] or none; first check arr[hi]
-    u32 top = arr(hi);
-    if (!(top > thr)) return hi + 1;
+    // invariant: answer in (lo, hi] or none; first check arr[hi] (unless the caller has)
+    if (!top_known) {
+        u32 top = arr(hi);
+        if (!(top > thr)) return hi + 1;
+    }
     // 256-ary steps: every lane probes 4 positions (independent loads), so a level costs one
     // memory latency and 46 M positions need 4 levels instead of 5 (this chain is pure latency)
     while (hi - lo > 1) {
@@ -203,7 +205,36 @@ __device__ u32 wave_search_gt(const ARR arr, u32 lo, u32 hi, u32 thr) {
     return hi;
 }
 
+// One probe level over (lo, hi] plus arr(lo) itself: narrows to (nlo, nhi] when arr(lo) <= thr <
+// arr(hi) (the first i with arr[i] > thr is then inside); false when the range does not bracket it.
+template <typename ARR>
+__device__ bool wave_bracket(const ARR arr, u32 lo, u32 hi, u32 thr, u32 *nlo, u32 *nhi) {
+    const int lane = lane_id();
+    const u32 width = hi - lo;
+    const u32 step = (width + 255) / 256;
+    const u32 vlo = arr(lo);
+    u32 best = 256;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        u32 p = (u32)lane * 4u + (u32)j;
+        u32 idx = lo + (p + 1) * step;
+        if (idx > hi || idx < lo) idx = hi;
+        bool pred = arr(idx) > thr;
+        u64 m = __ballot(pred);
+        if (m) best = min(best, (u32)(__ffsll((unsigned long long)m) - 1) * 4u + (u32)j);
+    }
+    if (vlo > thr || best == 256) return false;
+    u32 b = lo + (best + 1) * step;
+    if (b > hi || b < lo) b = hi;
+    *nlo = lo + best * step;
+    *nhi = b;
+    return true;
+}
+
 // serial chain over blocks; one wave.  starts[k] for k <= count (starts[count] = end of last).
+// The chain is pure memory latency (each block's start is the previous block's end), so a block
+// costs as few dependent loads as possible: the run-end probe also fetches the prefix it will need,
+// and the search first tries a narrow bracket around "as long as the previous block".
 __global__ __launch_bounds__(64) void k1_split(const u32 *__restrict__ rs,
                                                const u32 *__restrict__ Ploc,
                                                const u32 *__restrict__ agg_c, u32 n, u32 block_size,
@@ -211,18 +242,24 @@ __global__ __launch_bounds__(64) void k1_split(const u32 *__restrict__ rs,
                                                u32 *__restrict__ count_out) {
     const u32 limit = block_size - 6;
     const PrefixArr P{Ploc, agg_c};
-    u32 s = 0, cnt = 0;
+    u32 s = 0, cnt = 0, plen = 0, perr = 0;
     while (s < n && cnt < max_blocks) {
         if (lane_id() == 0) starts[cnt] = s;
-        // end of the maximal run containing s
-        // end of the run containing s: almost always within the next 64 bytes
-        u32 re0;
+        // end of the run containing s: almost always within the next 64 bytes; the same step
+        // fetches P(idx + 1), which is P(re0 + 1) for the lane that finds the run end
+        u32 re0, p_re0p1 = 0;
+        bool have_p = false;
         {
             const u32 idx = s + 1u + (u32)lane_id();
             const bool pred = idx <= n && rs[idx] > s;
+            const u32 pnext = (idx + 1u <= n) ? P(idx + 1u) : 0u;
             const u64 m = __ballot(pred);
-            if (m) re0 = s + (u32)__ffsll((unsigned long long)m);
-            else re0 = (s + 64u >= n) ? n + 1u : wave_search_gt(PlainArr{rs}, s + 64u, n, s);
+            if (m) {
+                const int l0 = __ffsll((unsigned long long)m) - 1;
+                re0 = s + 1u + (u32)l0;
+                p_re0p1 = __shfl(pnext, l0, 64);
+                have_p = re0 + 1u <= n;
+            } else re0 = (s + 64u >= n) ? n + 1u : wave_search_gt(PlainArr{rs}, s + 64u, n, s);
         }
         if (re0 > n) re0 = n;
         u32 e;
@@ -241,12 +278,25 @@ __global__ __launch_bounds__(64) void k1_split(const u32 *__restrict__ rs,
             if (enc0 > limit) {
                 e = re0 + 1; // the first run alone overfills: refused right after the next head
             } else {
-                u32 thr = limit - enc0 + P(re0 + 1);
-                e = wave_search_gt(P, re0, hi, thr);
+                const u32 thr = limit - enc0 + (have_p ? p_re0p1 : P(re0 + 1));
+                // blocks of one kind of data are about equally long: bracket around the last length
+                u32 nlo = 0, nhi = 0;
+                bool br = false;
+                if (plen) {
+                    // as wide as the last prediction was wrong (x4), at least 1.5 % of the length
+                    const u32 half = min(max(2048u, 4u * perr + plen / 64u), max(2048u, plen / 2u));
+                    const u32 c = s + plen;
+                    const u32 lo2 = max(re0, c > half ? c - half : 0u);
+                    const u32 hi2 = (u32)min((u64)hi, (u64)c + half);
+                    if (lo2 < hi2) br = wave_bracket(P, lo2, hi2, thr, &nlo, &nhi);
+                }
+                e = br ? wave_search_gt(P, nlo, nhi, thr, true) : wave_search_gt(P, re0, hi, thr);
                 if (e > hi) e = (hi == n) ? n : hi; // not expected when hi < n
             }
         }
         cnt++;
+        perr = (e - s > plen) ? (e - s - plen) : (plen - (e - s));
+        plen = e - s;
         s = e;
     }
     if (lane_id() == 0) {
