@@ -17,9 +17,10 @@
 //                   ruler chain from the origin and gives each ruler its output offset, c) each
 //                   ruler walks again and writes its bytes.  A walk that returns to the origin before
 //                   n steps (block = w^k: k cycles) is written once and replicated (kd_cycfill).
-//   kd_unrle      : final run-length decoding, a wave per block over rows of 64 bytes: which bytes
-//                   are repeat counts is a 2-state automaton over runs of equal bytes (state = "the
-//                   next byte is a count"), scanned inside the row by function composition
+//   kd_unrle_*    : final run-length decoding over rows of 64 bytes: which bytes are repeat counts
+//                   is a 2-state automaton over runs of equal bytes (state = "the next byte is a
+//                   count"), scanned inside the row by function composition; a block is cut at run
+//                   heads into 16 pieces, each counted for both entry states, resolved, then written
 //   k1_crc_p1/p2  : block CRCs of the decoded bytes (the encoder's kernels)
 // Randomised blocks (S/BZip2BlockDecompressor.swift:367-374) are not supported: BZ2HIP_E_RANDOMISED.
 #include "ctx.hpp"
@@ -681,20 +682,16 @@ __device__ __forceinline__ u32 kd_fcompose(u32 a, u32 b) { // a earlier, b later
     return ((b >> (a & 1u)) & 1u) | (((b >> ((a >> 1) & 1u)) & 1u) << 1);
 }
 
+#define KD_SEGS 16 // a block's bytes are cut at run heads into up to 16 pieces, one wave each
+
+// One piece [a, e) of a block (a is a run head, e a run head or n), entered in state s_in with the
+// output offset off: returns the state after it and advances off; WRITE stores the bytes.
 template <bool WRITE>
-__global__ __launch_bounds__(64) void kd_unrle(const u8 *__restrict__ tt, const u32 *__restrict__ nArr,
-                                               u32 S, u32 *__restrict__ outlen,
-                                               u32 *__restrict__ flags, const u32 *__restrict__ outbase,
-                                               u8 *__restrict__ out) {
-    const u32 b = blockIdx.x;
+__device__ __forceinline__ u32 kd_unrle_range(const u8 *__restrict__ p, u32 a, u32 e, u32 n, u32 S,
+                                              u32 s_in, u32 &off, bool &overflow, u8 *__restrict__ o) {
     const int lane = lane_id();
-    const u32 n = nArr[b];
-    const u8 *p = tt + (size_t)b * S;
-    u8 *o = WRITE ? out + outbase[b] : nullptr;
-    u32 carry_prev = 256, carry_rs = 0, s_in = 0;
-    u32 off = 0;
-    bool overflow = false;
-    for (u32 rb4 = 0; rb4 < n; rb4 += 256) {
+    u32 carry_prev = 256, carry_rs = a;
+    for (u32 rb4 = a; rb4 < e; rb4 += 256) {
       // four rows of loads in flight (clamped addresses: the slot is padded), then the rows in turn
       u32 vq[4], nq[4];
 #pragma unroll
@@ -706,14 +703,14 @@ __global__ __launch_bounds__(64) void kd_unrle(const u8 *__restrict__ tt, const 
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const u32 rowbase = rb4 + r * 64;
-        if (rowbase >= n) break;
+        if (rowbase >= e) break;
         const u32 t = rowbase + lane;
-        const bool act = t < n;
+        const bool act = t < e;
         const u32 v = act ? vq[r] : 0u;
-        const u32 nxt = (t + 1 < n) ? nq[r] : 256u;
+        const u32 nxt = (t + 1 < n) ? nq[r] : 256u; // p[e] starts another run: the piece's last run ends at e
         u32 pv = __shfl_up(v, 1, 64);
         if (lane == 0) pv = carry_prev;
-        const bool head = act && (t == 0 || v != pv);
+        const bool head = act && (t == a || v != pv);
         u32 hs = head ? t + 1 : 0u;
         hs = wave_incl_scan_max(hs);
         const u32 rs = max(hs, carry_rs + 1) - 1; // start of the run this byte belongs to
@@ -723,8 +720,8 @@ __global__ __launch_bounds__(64) void kd_unrle(const u8 *__restrict__ tt, const 
         if (end) F = ((Lr % 5u) == 4u ? 1u : 0u) | (((Lr - 1u) % 5u) == 4u ? 2u : 0u);
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            const u32 e = __shfl_up(F, d, 64);
-            if (lane >= d) F = kd_fcompose(e, F);
+            const u32 g = __shfl_up(F, d, 64);
+            if (lane >= d) F = kd_fcompose(g, F);
         }
         u32 Fx = __shfl_up(F, 1, 64);
         if (lane == 0) Fx = 2u;
@@ -738,12 +735,14 @@ __global__ __launch_bounds__(64) void kd_unrle(const u8 *__restrict__ tt, const 
         if (WRITE) {
             const u32 my = off + inc - contrib;
             if (act && !is_count) o[my] = (u8)v;
-            // a count: the whole wave writes its copies
+            // a count: the whole wave writes its copies (of the byte before it; for the first byte
+            // of a piece that is the last byte of the piece before)
+            const u32 rb = (t == a && a > 0) ? (u32)p[a - 1] : pv;
             u64 cm = __ballot(is_count && v > 0);
             while (cm) {
                 const int i = __ffsll((unsigned long long)cm) - 1;
                 cm &= cm - 1;
-                const u32 cnt = __shfl(v, i, 64), at = __shfl(my, i, 64), byte = __shfl(pv, i, 64);
+                const u32 cnt = __shfl(v, i, 64), at = __shfl(my, i, 64), byte = __shfl(rb, i, 64);
                 for (u32 q = lane; q < cnt; q += 64) o[at + q] = (u8)byte;
             }
         }
@@ -753,10 +752,88 @@ __global__ __launch_bounds__(64) void kd_unrle(const u8 *__restrict__ tt, const 
         carry_rs = __shfl(rs, 63, 64);
       }
     }
-    if (!WRITE && lane == 0) {
-        outlen[b] = off;
-        flags[b] = (s_in ? 1u : 0u) | (overflow ? 2u : 0u); // 1: the block ends where a count is due
+    return s_in;
+}
+
+// piece k of a block starts at the first run head at or after k * ceil(n / KD_SEGS)
+__global__ __launch_bounds__(64) void kd_segs(const u8 *__restrict__ tt, const u32 *__restrict__ nArr,
+                                              u32 S, u32 *__restrict__ segstart) {
+    const u32 b = blockIdx.y, k = blockIdx.x;
+    const u32 n = nArr[b];
+    const u8 *p = tt + (size_t)b * S;
+    u32 pos = (u32)(((u64)k * n + KD_SEGS - 1) / KD_SEGS);
+    u32 found = n;
+    if (k == 0) found = 0;
+    else {
+        while (pos < n) {
+            const u32 t = pos + lane_id();
+            const bool hd = t < n && p[t] != p[t - 1]; // t >= 1 here
+            const u64 m = __ballot(hd);
+            if (m) { found = pos + (u32)__ffsll((unsigned long long)m) - 1u; break; }
+            pos += 64;
+        }
     }
+    if (lane_id() == 0) {
+        segstart[(size_t)b * (KD_SEGS + 1) + k] = found;
+        if (k == 0) segstart[(size_t)b * (KD_SEGS + 1) + KD_SEGS] = n;
+    }
+}
+
+// per piece and entry state: state after it and bytes it expands to
+__global__ __launch_bounds__(64) void kd_unrle_count(const u8 *__restrict__ tt,
+                                                     const u32 *__restrict__ nArr, u32 S,
+                                                     const u32 *__restrict__ segstart,
+                                                     u32 *__restrict__ segres) {
+    const u32 b = blockIdx.y, k = blockIdx.x;
+    const u32 n = nArr[b];
+    const u8 *p = tt + (size_t)b * S;
+    const u32 a = segstart[(size_t)b * (KD_SEGS + 1) + k], e = segstart[(size_t)b * (KD_SEGS + 1) + k + 1];
+    u32 len0 = 0, len1 = 0;
+    bool ov = false;
+    const u32 x0 = kd_unrle_range<false>(p, a, e, n, S, 0u, len0, ov, nullptr);
+    const u32 x1 = kd_unrle_range<false>(p, a, e, n, S, 1u, len1, ov, nullptr);
+    if (lane_id() == 0) {
+        u32 *r = segres + ((size_t)b * KD_SEGS + k) * 4;
+        r[0] = x0 | (x1 << 1) | (ov ? 4u : 0u);
+        r[1] = len0;
+        r[2] = len1;
+    }
+}
+
+// per block: entry state and output offset of every piece; the block's length and flags
+__global__ void kd_unrle_resolve(const u32 *__restrict__ segres, u32 *__restrict__ segin,
+                                 u32 *__restrict__ outlen, u32 *__restrict__ flags, u32 nb) {
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    u32 st = 0, off = 0;
+    bool ov = false;
+    for (u32 k = 0; k < KD_SEGS; k++) {
+        const u32 *r = segres + ((size_t)b * KD_SEGS + k) * 4;
+        segin[((size_t)b * KD_SEGS + k) * 2] = st;
+        segin[((size_t)b * KD_SEGS + k) * 2 + 1] = off;
+        const u32 len = st ? r[2] : r[1];
+        if (off + len < off || (r[0] & 4u)) ov = true;
+        off += len;
+        st = (r[0] >> st) & 1u;
+    }
+    outlen[b] = off;
+    flags[b] = (st ? 1u : 0u) | (ov ? 2u : 0u); // 1: the block ends where a count is due
+}
+
+__global__ __launch_bounds__(64) void kd_unrle_write(const u8 *__restrict__ tt,
+                                                     const u32 *__restrict__ nArr, u32 S,
+                                                     const u32 *__restrict__ segstart,
+                                                     const u32 *__restrict__ segin,
+                                                     const u32 *__restrict__ outbase,
+                                                     u8 *__restrict__ out) {
+    const u32 b = blockIdx.y, k = blockIdx.x;
+    const u32 n = nArr[b];
+    const u8 *p = tt + (size_t)b * S;
+    const u32 a = segstart[(size_t)b * (KD_SEGS + 1) + k], e = segstart[(size_t)b * (KD_SEGS + 1) + k + 1];
+    u32 off = segin[((size_t)b * KD_SEGS + k) * 2 + 1];
+    bool ov = false;
+    (void)kd_unrle_range<true>(p, a, e, n, S, segin[((size_t)b * KD_SEGS + k) * 2], off, ov,
+                               out + outbase[b]);
 }
 
 // ------------------------------------------------------------------ host driver
@@ -850,6 +927,8 @@ int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size
     u32 *d_nvis = D.get<u32>(NB), *d_cyc = D.get<u32>(NB);
     u32 *d_outlen = D.get<u32>(NB), *d_flags = D.get<u32>(NB), *d_outbase = D.get<u32>(NB + 1);
     u32 *d_crc = D.get<u32>(NB);
+    u32 *d_segstart = D.get<u32>((size_t)NB * (KD_SEGS + 1)), *d_segres = D.get<u32>((size_t)NB * KD_SEGS * 4);
+    u32 *d_segin = D.get<u32>((size_t)NB * KD_SEGS * 2);
     u32 *d_cagg = nullptr;
     size_t cagg_cap = 0;
     std::vector<u32> meta((size_t)NB * KM_WORDS);
@@ -914,7 +993,11 @@ int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size
                 kd_cycfill<<<dim3(64, nb), 256, 0, st>>>(d_n, d_cyc, S, d_tt);
                 KCHECK();
             }
-            kd_unrle<false><<<nb, 64, 0, st>>>(d_tt, d_n, S, d_outlen, d_flags, nullptr, nullptr);
+            kd_segs<<<dim3(KD_SEGS, nb), 64, 0, st>>>(d_tt, d_n, S, d_segstart);
+            KCHECK();
+            kd_unrle_count<<<dim3(KD_SEGS, nb), 64, 0, st>>>(d_tt, d_n, S, d_segstart, d_segres);
+            KCHECK();
+            kd_unrle_resolve<<<(nb + 63) / 64, 64, 0, st>>>(d_segres, d_segin, d_outlen, d_flags, nb);
             KCHECK();
             std::vector<u32> h_outlen(nb), h_flags(nb);
             HIPCHK(hipMemcpyAsync(h_outlen.data(), d_outlen, nb * 4, hipMemcpyDeviceToHost, st));
@@ -947,7 +1030,7 @@ int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size
             if (good) {
                 u8 *o = d_out + out_total;
                 HIPCHK(hipMemcpyAsync(d_outbase, h_base.data(), (good + 1) * 4, hipMemcpyHostToDevice, st));
-                kd_unrle<true><<<good, 64, 0, st>>>(d_tt, d_n, S, nullptr, nullptr, d_outbase, o);
+                kd_unrle_write<<<dim3(KD_SEGS, good), 64, 0, st>>>(d_tt, d_n, S, d_segstart, d_segin, d_outbase, o);
                 KCHECK();
                 const u32 ETPB = (maxlen + 4095) / 4096 + 1;
                 if ((size_t)good * ETPB > cagg_cap) {
