@@ -188,7 +188,7 @@ def main():
         res["decode"] = {"value": round(n_in / td / 1e6, 1), "unit": "MB/s", "ms": round(td * 1e3, 1),
                          "ok": bool(drc == 0 and dn == n_in and torch.equal(d_back[:dn], d_in))}
         del d_back
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:  # the CPU baseline is timed at N = 1 only
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import orc  # CPU oracle: test infrastructure, used here only as the timed baseline
             sample = data[: min(n_in, args.cpu_sample_mib << 20)]
