@@ -448,22 +448,28 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                 const u32 pk = (pq >> 2) | ((pq & 3u) << 11); // lane | byte shift << 8
                 bool room = len + avail <= block_size;
                 for (u32 q = 0; q < avail && !done; q++) {
-                    if (((plain >> q) & 1ull) && rep == 0 && room) {
-                        // the common case: one MTF symbol, no run pending (kd_index_to_front inlined)
-                        const u32 k2 = __builtin_amdgcn_readlane(pk, (int)q);
-                        const int src = (int)(k2 & 255u);
-                        const u32 sh = k2 >> 8;
-                        const u32 v = (__builtin_amdgcn_readlane(L, src) >> sh) & 255u;
-                        const u32 up = (u32)__builtin_amdgcn_update_dpp(0, (int)L, 0x138, 0xf, 0xf, false);
-                        const u32 shifted = (L << 8) | ((lane == 0) ? v : (up >> 24));
-                        const u32 m = 0xffffffffu >> (24u - sh); // bytes 0..k of the source lane's word move
-                        const u32 at_src = (shifted & m) | (L & ~m);
-                        L = (lane < src) ? shifted : ((lane == src) ? at_src : L);
-                        curbyte = v;
-                        if ((u32)lane == (len & 63u)) pend = v;
-                        len++;
-                        if ((len & 63u) == 0) out[len - 64u + lane] = (u8)pend;
-                        continue;
+                    if (rep == 0 && room) {
+                        // the common case: a stretch of plain MTF symbols, no run pending
+                        // (kd_index_to_front inlined; the stretch's length comes from the ballot)
+                        const u64 rest = ~(plain >> q);
+                        const u32 np = rest ? (u32)__builtin_ctzll(rest) : 64u;
+                        const u32 qe = q + np; // <= avail: entries past avail are not plain
+                        for (; q < qe; q++) {
+                            const u32 k2 = __builtin_amdgcn_readlane(pk, (int)q);
+                            const int src = (int)(k2 & 255u);
+                            const u32 sh = k2 >> 8;
+                            const u32 v = (__builtin_amdgcn_readlane(L, src) >> sh) & 255u;
+                            const u32 up = (u32)__builtin_amdgcn_update_dpp(0, (int)L, 0x138, 0xf, 0xf, false);
+                            const u32 shifted = (L << 8) | ((lane == 0) ? v : (up >> 24));
+                            const u32 m = 0xffffffffu >> (24u - sh); // bytes 0..k of the source lane's word move
+                            const u32 at_src = (shifted & m) | (L & ~m);
+                            L = (lane < src) ? shifted : ((lane == src) ? at_src : L);
+                            curbyte = v;
+                            if ((u32)lane == (len & 63u)) pend = v;
+                            len++;
+                            if ((len & 63u) == 0) out[len - 64u + lane] = (u8)pend;
+                        }
+                        if (q >= avail) break;
                     }
                     const u32 sym = __builtin_amdgcn_readlane(mine, (int)q);
                     if (sym & KD_SYM_ERR) { status = sym & 0xffu; done = true; break; }
