@@ -526,38 +526,50 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
 
 // ------------------------------------------------------------------ inverse BWT
 // per-block list of the slots to work on: slot[k] = candidate index, nArr / orig per chain block
+#define KD_MPARTS 8 // the counting sort of a block runs as 8 waves over 8 index ranges
+__device__ __forceinline__ u32 kd_part_len(u32 n) { return (((n + KD_MPARTS - 1) / KD_MPARTS) + 255u) & ~255u; }
+
+// base[part][v] = first merged slot of byte v for the indices of that part
 __global__ __launch_bounds__(256) void kd_hist(const u8 *__restrict__ bwt, const u32 *__restrict__ slot,
                                                const u32 *__restrict__ nArr, u32 S,
                                                u32 *__restrict__ base) {
     const u32 b = blockIdx.x;
-    __shared__ u32 h[256];
+    __shared__ u32 h[KD_MPARTS][256];
     __shared__ u32 sm[8];
-    h[threadIdx.x] = 0;
+    for (int q = 0; q < KD_MPARTS; q++) h[q][threadIdx.x] = 0;
     __syncthreads();
     const u8 *p = bwt + (size_t)slot[b] * S;
     const u32 n = nArr[b];
-    for (u32 i = threadIdx.x; i < n; i += 256) atomicAdd(&h[p[i]], 1u);
+    const u32 pl = kd_part_len(n);
+    for (u32 i = threadIdx.x; i < n; i += 256) atomicAdd(&h[i / pl][p[i]], 1u);
     __syncthreads();
+    u32 c[KD_MPARTS], sum = 0;
+    for (int q = 0; q < KD_MPARTS; q++) { c[q] = h[q][threadIdx.x]; sum += c[q]; }
     u32 tot;
-    const u32 ex = block_excl_scan_add<256>(h[threadIdx.x], sm, &tot);
-    base[(size_t)b * 256 + threadIdx.x] = ex;
+    u32 ex = block_excl_scan_add<256>(sum, sm, &tot);
+    for (int q = 0; q < KD_MPARTS; q++) {
+        base[((size_t)b * KD_MPARTS + q) * 256 + threadIdx.x] = ex;
+        ex += c[q];
+    }
 }
 
 // merged[base[v]++] = (i << 8) + v in index order (S/BZip2BlockDecompressor.swift:346-350); one wave
+// per part of the block
 __global__ __launch_bounds__(64) void kd_merge(const u8 *__restrict__ bwt, const u32 *__restrict__ slot,
                                                const u32 *__restrict__ nArr, u32 S,
                                                const u32 *__restrict__ base, u32 *__restrict__ merged) {
-    const u32 b = blockIdx.x;
+    const u32 b = blockIdx.y, part = blockIdx.x;
     const int lane = lane_id();
     __shared__ u32 run[256];
-    for (int q = lane; q < 256; q += 64) run[q] = base[(size_t)b * 256 + q];
+    for (int q = lane; q < 256; q += 64) run[q] = base[((size_t)b * KD_MPARTS + part) * 256 + q];
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
     const u8 *p = bwt + (size_t)slot[b] * S;
     u32 *mg = merged + (size_t)b * S;
-    const u32 n = nArr[b];
+    const u32 nn = nArr[b], pl = kd_part_len(nn);
+    const u32 n = min(nn, (part + 1u) * pl); // this part: [part * pl, n)
     const u64 lt = (1ull << lane) - 1ull;
-    for (u32 r0 = 0; r0 < n; r0 += 256) {
+    for (u32 r0 = part * pl; r0 < n; r0 += 256) {
         u32 vv[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -927,7 +939,7 @@ int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size
     u8 *d_bwt = D.get<u8>((size_t)NB * S), *d_tt = D.get<u8>((size_t)NB * S);
     u32 *d_meta = D.get<u32>((size_t)NB * KM_WORDS);
     u32 *d_slot = D.get<u32>(NB), *d_n = D.get<u32>(NB), *d_orig = D.get<u32>(NB);
-    u32 *d_base = D.get<u32>((size_t)NB * 256);
+    u32 *d_base = D.get<u32>((size_t)NB * KD_MPARTS * 256);
     u32 *d_merged = D.get<u32>((size_t)NB * S);
     uint2 *d_rinfo = D.get<uint2>((size_t)NB * RS), *d_visits = D.get<uint2>((size_t)NB * RS);
     u32 *d_nvis = D.get<u32>(NB), *d_cyc = D.get<u32>(NB);
@@ -987,7 +999,7 @@ int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size
             if (maxn) {
                 kd_hist<<<nb, 256, 0, st>>>(d_bwt, d_slot, d_n, S, d_base);
                 KCHECK();
-                kd_merge<<<nb, 64, 0, st>>>(d_bwt, d_slot, d_n, S, d_base, d_merged);
+                kd_merge<<<dim3(KD_MPARTS, nb), 64, 0, st>>>(d_bwt, d_slot, d_n, S, d_base, d_merged);
                 KCHECK();
                 const dim3 gr((RS + 255) / 256, nb);
                 kd_walk_a<<<gr, 256, 0, st>>>(d_merged, d_n, d_orig, S, RS, d_rinfo);
