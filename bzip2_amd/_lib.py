@@ -23,6 +23,8 @@ SYMBOLS = [
     "bz2hip_stream_pending", "bz2hip_rle1_split", "bz2hip_bwt", "bz2hip_mtf_rle2",
     "bz2hip_huffman", "bz2hip_block_compress", "bz2hip_profile_reset", "bz2hip_profile_get", "bz2hip_last_stats3",
     "bz2hip_last_stats", "bz2hip_last_stats2", "bz2hip_decompress", "bz2hip_decompress_device",
+    "bz2hip_shard_scan", "bz2hip_shard_chain",
+    "bz2hip_shard_compress", "bz2hip_stitch_device",
 ]
 
 
@@ -48,6 +50,12 @@ def load():
     if not os.path.exists(SO_PATH):
         raise ImportError(f"{SO_PATH} missing: build it with `make -C bzip2_amd/csrc` "
                           "(there is no CPU fallback)")
+    # PyTorch-ROCm bundles its own libamdhip64; two HIP runtimes in one process do not see the GPU
+    # from the second one.  Loading torch's first makes libbz2hip.so resolve to the same runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(SO_PATH)
     vp, sz, u32p = C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)
     L.bz2hip_create.restype = C.c_int
@@ -104,6 +112,14 @@ def load():
     L.bz2hip_decompress.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
     L.bz2hip_decompress_device.restype = C.c_int
     L.bz2hip_decompress_device.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
+    L.bz2hip_shard_scan.restype = C.c_int
+    L.bz2hip_shard_scan.argtypes = [vp, vp, sz, C.c_int]
+    L.bz2hip_shard_chain.restype = C.c_int
+    L.bz2hip_shard_chain.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int, u32p, C.POINTER(C.c_uint64)]
+    L.bz2hip_shard_compress.restype = C.c_int
+    L.bz2hip_shard_compress.argtypes = [vp, vp, sz, C.POINTER(C.c_uint64), vp, C.c_uint32, u32p]
+    L.bz2hip_stitch_device.restype = C.c_int
+    L.bz2hip_stitch_device.argtypes = [vp, C.c_int, C.c_uint32, vp, vp, vp, vp, vp, sz, C.POINTER(sz)]
     _lib = L
     return L
 
@@ -205,6 +221,40 @@ class Context:
                                                        C.c_void_p(d_out_ptr), cap, C.byref(nbits),
                                                        _p(crcs), mx, C.byref(nb)))
         return nbits.value, crcs[: nb.value].copy()
+
+    # ---- one stream sharded over GPUs / processes (device pointers)
+    def shard_scan(self, d_in_ptr, avail, level):
+        self._chk(self.L.bz2hip_shard_scan(self.h, C.c_void_p(d_in_ptr), avail, level))
+
+    def shard_chain(self, first, limit, final):
+        """-> (n_blocks, next): blocks starting in [first, limit); next = where the next shard continues"""
+        nb = C.c_uint32(0)
+        nxt = C.c_uint64(0)
+        self._chk(self.L.bz2hip_shard_chain(self.h, first, limit, int(bool(final)), C.byref(nb), C.byref(nxt)))
+        return nb.value, nxt.value
+
+    def shard_compress(self, d_out_ptr, cap, max_blocks):
+        """-> (nbits, crcs) of the blocks found by the last shard_chain, bit-abutted from bit 0"""
+        crcs = np.zeros(max(max_blocks, 1), dtype=np.uint32)
+        nb = C.c_uint32(0)
+        nbits = C.c_uint64(0)
+        self._chk(self.L.bz2hip_shard_compress(self.h, C.c_void_p(d_out_ptr), cap, C.byref(nbits), _p(crcs),
+                                               max_blocks, C.byref(nb)))
+        return nbits.value, crcs[: nb.value].copy()
+
+    def stitch_device(self, level, segments, d_out_ptr, cap):
+        """segments: list of (device pointer, nbits, crcs uint32 array) in block order -> stream length"""
+        n = len(segments)
+        crcs = [np.ascontiguousarray(s[2], dtype=np.uint32) for s in segments]
+        crcs_nz = [c if c.size else np.zeros(1, dtype=np.uint32) for c in crcs]
+        pb = (C.c_void_p * max(n, 1))(*[int(s[0]) for s in segments])
+        pc = (C.c_void_p * max(n, 1))(*[c.ctypes.data for c in crcs_nz])
+        nbits = np.array([int(s[1]) for s in segments] + [0], dtype=np.uint64)
+        ncrc = np.array([c.size for c in crcs] + [0], dtype=np.uint32)
+        got = C.c_size_t(0)
+        self._chk(self.L.bz2hip_stitch_device(self.h, level, n, pb, _p(nbits), pc, _p(ncrc),
+                                              C.c_void_p(d_out_ptr), cap, C.byref(got)))
+        return got.value
 
     def compress_blocks(self, data, level):
         """host data -> (bits bytes, nbits, crcs)"""

@@ -11,14 +11,85 @@
 #define WMAX (1u << 30) // window of input scanned at once (u32 prefix sums stay < 2^32)
 
 // ------------------------------------------------------------------ workspace
-template <typename T>
-static T *dalloc(bz2hip_ctx *c, size_t count) {
-    void *p = nullptr;
-    size_t bytes = std::max<size_t>(count * sizeof(T), 256);
-    HIPCHK(hipMalloc(&p, bytes));
-    c->batch.allocs.push_back(p);
-    c->batch.bytes += bytes;
-    return (T *)p;
+// A batch workspace is ONE device region carved into its arrays (256-byte aligned each), so that
+// it either exists completely or not at all: capacities are published only after the allocation
+// has succeeded, and a failed allocation leaves an empty batch (NB = 0) that the next call
+// rebuilds.  The same carving serves the allocation-free entry point (region = the static
+// scratch array, bz2hip_compress_device_noalloc below).
+struct Carver {
+    u8 *base;        // nullptr: count only
+    size_t off = 0;
+    template <typename T>
+    T *get(size_t count) {
+        const size_t bytes = (std::max<size_t>(count * sizeof(T), 256) + 255) & ~(size_t)255;
+        T *p = base ? (T *)(base + off) : nullptr;
+        off += bytes;
+        return p;
+    }
+};
+
+static u32 slot_elems(int level) {
+    return (u32)(((size_t)level * 100000 + 8 + RTILE - 1) / RTILE * RTILE);
+}
+
+// fills N's pointers from `base` (or only counts when base == nullptr); returns the bytes used
+static size_t layout_batch(Batch &N, int level, int nb_blocks, u8 *base) {
+    Carver A{base};
+    const u32 S = slot_elems(level);
+    N.NB = nb_blocks;
+    N.S = S;
+    N.level = level;
+    N.TPB = S / RTILE;
+    const size_t nb = (size_t)nb_blocks;
+    const size_t S2 = S + 64;
+    N.T = A.get<u8>(nb * S);
+    N.n = A.get<u32>(nb);
+    N.present = A.get<u32>(nb * 8);
+    N.crc = A.get<u32>(nb);
+    N.keyA = A.get<u64>(nb * S);
+    N.keyB = A.get<u64>(nb * S);
+    N.slA = A.get<u64>(nb * S);
+    N.slB = A.get<u64>(nb * S);
+    N.rank = A.get<u32>(nb * S);
+    N.mS = A.get<u32>(nb); N.mL = A.get<u32>(nb); N.mSn = A.get<u32>(nb); N.mLn = A.get<u32>(nb);
+    N.hcur = A.get<u32>(nb); N.huse = A.get<u32>(nb); N.state = A.get<u32>(nb);
+    N.par = A.get<u32>(nb); N.leftg = A.get<u32>(nb);
+    N.tilehist = A.get<u32>(nb * N.TPB * 256);
+    N.digitbase = A.get<u32>(nb * 256);
+    N.tileagg = A.get<u32>(nb * N.TPB * 4);
+    N.pvote = A.get<u32>(nb * 8192 * 2);
+    N.cand = A.get<u32>(nb * 2);
+    N.vagg = A.get<u32>(nb * 2 * N.TPB * 2);
+    N.runs = A.get<u32>(nb * 68);
+    N.nheads = A.get<u32>(nb);
+    N.active = A.get<u32>(nb);
+    N.rounds = A.get<u32>(nb);
+    N.ctl = A.get<u32>(64);
+    N.bwt = A.get<u8>(nb * S);
+    N.orig = A.get<u32>(nb);
+    N.periodic = A.get<u32>(nb);
+    N.mtfrec = A.get<u8>(nb * (S / MTF_CHUNK) * 256);
+    N.mtfcnt = A.get<u32>(nb * (S / MTF_CHUNK));
+    N.mtfpos = A.get<u8>(nb * S);
+    N.r2agg = A.get<u32>(nb * N.TPB * 4);
+    N.mtf = A.get<u16>(nb * S2);
+    N.mtflen = A.get<u32>(nb);
+    N.alpha = A.get<u32>(nb);
+    N.freq = A.get<u32>(nb * 264);
+    N.ntables = A.get<u32>(nb);
+    N.hlen = A.get<u8>(nb * MAX_TABLES * 264);
+    N.hpart = A.get<u32>(nb * HS_PART_MAX * MAX_TABLES * 264);
+    N.hfreq = A.get<u32>(nb * MAX_TABLES * 264);
+    N.hcode = A.get<u32>(nb * MAX_TABLES * 264);
+    N.sel = A.get<u8>(nb * SEL_STRIDE);
+    N.selpos = A.get<u8>(nb * SEL_STRIDE);
+    N.nsel = A.get<u32>(nb);
+    N.tblbits = A.get<u64>(nb * MAX_TABLES * 2);
+    N.hdrbits = A.get<u64>(nb * 4);
+    N.bitoff = A.get<u64>(2 * (nb + 1));
+    N.pkagg = A.get<u32>(nb * ((S2 + PK_TILE - 1) / PK_TILE));
+    N.bytes = A.off;
+    return A.off;
 }
 
 static void dfree_all(bz2hip_ctx *c) {
@@ -28,108 +99,88 @@ static void dfree_all(bz2hip_ctx *c) {
 
 static void ensure_batch(bz2hip_ctx *c, int level, int nb_needed) {
     Batch &B = c->batch;
-    const u32 S = (u32)(((size_t)level * 100000 + 8 + RTILE - 1) / RTILE * RTILE);
+    const u32 S = slot_elems(level);
+    if (c->fixed_ws) {
+        // allocation-free call: the workspace was carved from the static scratch for this level
+        if (B.NB < 1 || B.S != S) throw HipError(BZ2HIP_E_STATE, "internal: fixed workspace does not fit the level");
+        return;
+    }
     int cap = c->opts.max_batch_blocks > 0 ? c->opts.max_batch_blocks : DEFAULT_BATCH_BLOCKS;
     int want = std::min(cap, std::max(nb_needed, 1));
     if (B.NB >= want && B.S == S) return;
     want = std::max(want, B.S == S ? B.NB : 0);
-    // free the old batch (window scratch is tracked separately)
+    // free the old batch (window scratch is tracked separately); the context holds an empty batch
+    // (NB = 0) until the new region exists, so a failed allocation cannot leave stale capacities
     dfree_all(c);
-    Batch &N = c->batch;
-    N.NB = want;
-    N.S = S;
-    N.level = level;
-    N.TPB = S / RTILE;
-    const size_t nb = (size_t)want;
-    const size_t S2 = S + 64;
-    N.T = dalloc<u8>(c, nb * S);
-    N.n = dalloc<u32>(c, nb);
-    N.present = dalloc<u32>(c, nb * 8);
-    N.crc = dalloc<u32>(c, nb);
-    N.keyA = dalloc<u64>(c, nb * S);
-    N.keyB = dalloc<u64>(c, nb * S);
-    N.slA = dalloc<u64>(c, nb * S);
-    N.slB = dalloc<u64>(c, nb * S);
-    N.rank = dalloc<u32>(c, nb * S);
-    N.mS = dalloc<u32>(c, nb); N.mL = dalloc<u32>(c, nb); N.mSn = dalloc<u32>(c, nb); N.mLn = dalloc<u32>(c, nb);
-    N.hcur = dalloc<u32>(c, nb); N.huse = dalloc<u32>(c, nb); N.state = dalloc<u32>(c, nb);
-    N.par = dalloc<u32>(c, nb); N.leftg = dalloc<u32>(c, nb);
-    N.tilehist = dalloc<u32>(c, nb * N.TPB * 256);
-    N.digitbase = dalloc<u32>(c, nb * 256);
-    N.tileagg = dalloc<u32>(c, nb * N.TPB * 4);
-    N.pvote = dalloc<u32>(c, nb * 8192 * 2);
-    N.cand = dalloc<u32>(c, nb * 2);
-    N.vagg = dalloc<u32>(c, nb * 2 * N.TPB * 2);
-    N.runs = dalloc<u32>(c, nb * 68);
-    N.nheads = dalloc<u32>(c, nb);
-    N.active = dalloc<u32>(c, nb);
-    N.rounds = dalloc<u32>(c, nb);
-    N.ctl = dalloc<u32>(c, 64);
-    N.bwt = dalloc<u8>(c, nb * S);
-    N.orig = dalloc<u32>(c, nb);
-    N.periodic = dalloc<u32>(c, nb);
-    N.mtfrec = dalloc<u8>(c, nb * (S / MTF_CHUNK) * 256);
-    N.mtfcnt = dalloc<u32>(c, nb * (S / MTF_CHUNK));
-    N.mtfpos = dalloc<u8>(c, nb * S);
-    N.r2agg = dalloc<u32>(c, nb * N.TPB * 4);
-    N.mtf = dalloc<u16>(c, nb * S2);
-    N.mtflen = dalloc<u32>(c, nb);
-    N.alpha = dalloc<u32>(c, nb);
-    N.freq = dalloc<u32>(c, nb * 264);
-    N.ntables = dalloc<u32>(c, nb);
-    N.hlen = dalloc<u8>(c, nb * MAX_TABLES * 264);
-    N.hpart = dalloc<u32>(c, nb * HS_PART_MAX * MAX_TABLES * 264);
-    N.hfreq = dalloc<u32>(c, nb * MAX_TABLES * 264);
-    N.hcode = dalloc<u32>(c, nb * MAX_TABLES * 264);
-    N.sel = dalloc<u8>(c, nb * SEL_STRIDE);
-    N.selpos = dalloc<u8>(c, nb * SEL_STRIDE);
-    N.nsel = dalloc<u32>(c, nb);
-    N.tblbits = dalloc<u64>(c, nb * MAX_TABLES * 2);
-    N.hdrbits = dalloc<u64>(c, nb * 4);
-    N.bitoff = dalloc<u64>(c, 2 * (nb + 1));
-    N.pkagg = dalloc<u32>(c, nb * ((S2 + PK_TILE - 1) / PK_TILE));
-    HIPCHK(hipMemsetAsync(N.ctl, 0, 64 * sizeof(u32), c->stream));
+    Batch N;
+    const size_t bytes = layout_batch(N, level, want, nullptr);
+    void *region = nullptr;
+    HIPCHK(hipMalloc(&region, bytes)); // throws BZ2HIP_E_NOMEM; c->batch stays empty
+    layout_batch(N, level, want, (u8 *)region);
+    N.allocs.push_back(region);
+    c->batch = std::move(N);
+    HIPCHK(hipMemsetAsync(c->batch.ctl, 0, 64 * sizeof(u32), c->stream));
 }
 
 static void wfree(bz2hip_ctx *c) {
-    u32 **ps[] = {&c->w_rs, &c->w_P, &c->w_agg1, &c->w_agg2, &c->w_starts, &c->w_eagg, &c->w_cagg};
-    for (auto pp : ps) {
-        if (*pp) (void)hipFree(*pp);
-        *pp = nullptr;
-    }
     c->w_cap = 0;
+    c->w_maxblocks = 0;
     c->w_eagg_nb = 0;
+    if (c->w_region) (void)hipFree(c->w_region);
+    if (c->w_eregion) (void)hipFree(c->w_eregion);
+    c->w_region = c->w_eregion = nullptr;
+    c->w_rs = c->w_P = c->w_agg1 = c->w_agg2 = c->w_starts = c->w_eagg = c->w_cagg = nullptr;
 }
 
 static u32 window_max_blocks(size_t wlen, int level) {
     return (u32)(wlen / ((size_t)level * 50000) + 4);
 }
 
+static u32 emit_tiles_per_block(int level) {
+    return (u32)(((u64)level * 100000u * 52 + 2048) / 4096 + 2);
+}
+
+// window scratch: rs, P (u32 per input byte), tile aggregates, block starts
+static size_t layout_window(bz2hip_ctx *c, size_t wlen, u32 mb, u8 *base) {
+    Carver A{base};
+    const size_t tiles = (wlen + 4095) / 4096 + 2;
+    u32 *rs = A.get<u32>(wlen + 16), *P = A.get<u32>(wlen + 16);
+    u32 *a1 = A.get<u32>(tiles), *a2 = A.get<u32>(tiles), *st = A.get<u32>((size_t)mb + 8);
+    if (base) { c->w_rs = rs; c->w_P = P; c->w_agg1 = a1; c->w_agg2 = a2; c->w_starts = st; }
+    return A.off;
+}
+// per-batch emit / CRC tile partials
+static size_t layout_emit(bz2hip_ctx *c, int nb, u32 ETPB, u8 *base) {
+    Carver A{base};
+    u32 *e = A.get<u32>((size_t)nb * ETPB), *g = A.get<u32>((size_t)nb * ETPB);
+    if (base) { c->w_eagg = e; c->w_cagg = g; }
+    return A.off;
+}
+
 static void ensure_window(bz2hip_ctx *c, size_t wlen, int level) {
-    const u32 bs = (u32)level * 100000u;
-    const u32 ETPB = (u32)(((u64)bs * 52 + 2048) / 4096 + 2);
+    const u32 ETPB = emit_tiles_per_block(level);
     const u32 mb = window_max_blocks(wlen, level);
+    if (c->fixed_ws) {
+        if (c->w_cap < wlen || c->w_maxblocks < mb || c->w_eagg_nb < c->batch.NB || c->w_ETPB != ETPB)
+            throw HipError(BZ2HIP_E_STATE, "internal: fixed workspace does not fit the window");
+        return;
+    }
     if (c->w_cap < wlen || c->w_maxblocks < mb) {
-        u32 **ps[] = {&c->w_rs, &c->w_P, &c->w_agg1, &c->w_agg2, &c->w_starts};
-        for (auto pp : ps) {
-            if (*pp) (void)hipFree(*pp);
-            *pp = nullptr;
-        }
-        const size_t tiles = (wlen + 4095) / 4096 + 2;
-        HIPCHK(hipMalloc((void **)&c->w_rs, (wlen + 16) * sizeof(u32)));
-        HIPCHK(hipMalloc((void **)&c->w_P, (wlen + 16) * sizeof(u32)));
-        HIPCHK(hipMalloc((void **)&c->w_agg1, tiles * sizeof(u32)));
-        HIPCHK(hipMalloc((void **)&c->w_agg2, tiles * sizeof(u32)));
-        HIPCHK(hipMalloc((void **)&c->w_starts, ((size_t)mb + 8) * sizeof(u32)));
+        c->w_cap = 0; // nothing is published until the new region exists
+        c->w_maxblocks = 0;
+        if (c->w_region) (void)hipFree(c->w_region);
+        c->w_region = nullptr;
+        HIPCHK(hipMalloc(&c->w_region, layout_window(c, wlen, mb, nullptr)));
+        layout_window(c, wlen, mb, (u8 *)c->w_region);
         c->w_cap = wlen;
         c->w_maxblocks = mb;
     }
     if (c->w_eagg_nb < c->batch.NB || c->w_ETPB != ETPB) {
-        if (c->w_eagg) (void)hipFree(c->w_eagg);
-        if (c->w_cagg) (void)hipFree(c->w_cagg);
-        c->w_eagg = c->w_cagg = nullptr;
-        HIPCHK(hipMalloc((void **)&c->w_eagg, (size_t)c->batch.NB * ETPB * sizeof(u32)));
-        HIPCHK(hipMalloc((void **)&c->w_cagg, (size_t)c->batch.NB * ETPB * sizeof(u32)));
+        c->w_eagg_nb = 0;
+        if (c->w_eregion) (void)hipFree(c->w_eregion);
+        c->w_eregion = nullptr;
+        HIPCHK(hipMalloc(&c->w_eregion, layout_emit(c, c->batch.NB, ETPB, nullptr)));
+        layout_emit(c, c->batch.NB, ETPB, (u8 *)c->w_eregion);
         c->w_eagg_nb = c->batch.NB;
         c->w_ETPB = ETPB;
     }
@@ -137,12 +188,14 @@ static void ensure_window(bz2hip_ctx *c, size_t wlen, int level) {
 
 static void ensure_staging(bz2hip_ctx *c, size_t in_bytes, size_t out_bytes) {
     if (c->h_in_cap < in_bytes) {
+        c->h_in_cap = 0;
         if (c->h_in) (void)hipFree(c->h_in);
         c->h_in = nullptr;
         HIPCHK(hipMalloc((void **)&c->h_in, in_bytes + 64));
         c->h_in_cap = in_bytes;
     }
     if (c->h_out_cap < out_bytes) {
+        c->h_out_cap = 0;
         if (c->h_out) (void)hipFree(c->h_out);
         c->h_out = nullptr;
         HIPCHK(hipMalloc((void **)&c->h_out, out_bytes + 64));
@@ -184,6 +237,11 @@ extern "C" size_t bz2hip_compress_bound(size_t n) {
 
 static std::string g_create_err = "no error";
 
+static int env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
 extern "C" int bz2hip_create(bz2hip_ctx **out, const bz2hip_opts *opts) {
     if (!out) return BZ2HIP_E_PARAM;
     *out = nullptr;
@@ -211,11 +269,24 @@ extern "C" int bz2hip_create(bz2hip_ctx **out, const bz2hip_opts *opts) {
         delete c;
         return BZ2HIP_E_HIP;
     }
+    // the environment is read here, once per context (experiments only; never on the call path)
+    c->lanes = env_int("BZ2HIP_LANES", 2);
+    c->debug = env_int("BZ2HIP_DEBUG", 0);
+    c->plain_mask = (u32)env_int("BZ2HIP_PLAIN", 2);
+    c->r0bits = (u32)env_int("BZ2HIP_R0BITS", 40);
+    c->r0_sweeps = (u32)std::min(16, std::max(1, env_int("BZ2HIP_RSWEEPS", 2)));
     try {
         k1_init_tables(c);
+        HIPCHK(hipEventCreateWithFlags(&c->crc_done, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     } catch (const std::exception &e) {
         g_create_err = e.what();
+        if (c->crc_done) (void)hipEventDestroy(c->crc_done);
+        if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+        if (c->ev_join) (void)hipEventDestroy(c->ev_join);
         (void)hipStreamDestroy(c->stream);
+        (void)hipStreamDestroy(c->stream_other);
         delete c;
         return BZ2HIP_E_HIP;
     }
@@ -249,41 +320,132 @@ extern "C" const char *bz2hip_last_error(const bz2hip_ctx *c) {
 }
 
 // ------------------------------------------------------------------ the pipeline
+static void reset_stats(bz2hip_ctx *c) {
+    c->st_blocks = c->st_rounds = c->st_rle_bytes = c->st_periodic = 0;
+    c->st_sorted_elems = c->st_nr = c->st_s_elems = 0;
+    c->st_bwt_seconds = 0;
+    c->st_tie_traps = 0;
+}
+
+static int batch_cap(const bz2hip_ctx *c) {
+    return c->opts.max_batch_blocks > 0 ? c->opts.max_batch_blocks : DEFAULT_BATCH_BLOCKS;
+}
+
+// Sizes the workspace for a window of wlen bytes (batches of equal size, two lanes when the window
+// needs several batches) and launches the K1 scan over it.  Returns whether two lanes are used.
+static bool prepare_window(bz2hip_ctx *c, const u8 *d_win, size_t wlen, int level) {
+    const u32 bs = (u32)level * 100000u;
+    // Splitting one batch in two costs more than the overlap returns (measured: 221 blocks as
+    // 2 x 111 is 10 % slower), so the second lane is used only when the window needs several
+    // batches anyway.
+    const int est = (int)std::min<size_t>(wlen / (bs - 4) + 1, 1u << 20);
+    const int cap = batch_cap(c);
+    const bool two = est > cap && c->lanes >= 2 && !c->fixed_ws;
+    // equal batches: ceil(est / number of batches), not cap + remainder
+    const int per = (est + (est + cap - 1) / cap - 1) / ((est + cap - 1) / cap);
+    ensure_batch(c, level, per);
+    if (two) {
+        c->swap_lane();
+        ensure_batch(c, level, per);
+        c->swap_lane();
+    }
+    ensure_window(c, wlen, level);
+    run_scan(c, d_win, (u32)wlen, c->w_rs, c->w_P, c->w_agg1, c->w_agg2);
+    return two;
+}
+
+struct FrameState {
+    u8 *d_out;
+    size_t out_cap;
+    u64 *bitpos;
+    u32 *stream_crc;
+    int level;
+    bool wrote_header; // false: the first frame writes "BZh" + level at bit 0
+    bool any_frame;
+    std::vector<u32> *crcs_out;
+};
+
+// Compresses blocks [0, usable) of a scanned window (starts = their window-relative offsets) into
+// F.d_out at bit *F.bitpos: batches of equal size, alternating lanes; pack + frame of batch k (which
+// need the bit cursor, i.e. host round trips) are issued after the BWT of batch k + 1 has been
+// driven, so batch k's MTF / Huffman kernels overlap that BWT on the other stream.
+static void compress_window_blocks(bz2hip_ctx *c, const u8 *d_win, const std::vector<u32> &starts, u32 usable,
+                                   bool two, bool trailer_after_last, FrameState &F) {
+    const u32 bs = (u32)F.level * 100000u;
+    const u32 nbat = (usable + (u32)c->batch.NB - 1) / (u32)c->batch.NB;
+    const u32 bsz = (usable + nbat - 1) / nbat;
+    struct Pending { bool valid; int lane; int nb; bool is_last; } pend = {false, 0, 0, false};
+    auto finish = [&](const Pending &P) {
+        if (c->active_lane != P.lane) c->swap_lane();
+        Batch &B = c->batch;
+        const int nb = P.nb;
+        run_pack(c, nb, bs + 1, F.d_out, *F.bitpos, false, 0, F.out_cap, nullptr);
+        u64 endbit;
+        u32 crc_out;
+        run_frame(c, nb, F.d_out, F.level, !F.wrote_header, P.is_last, *F.stream_crc, &endbit, &crc_out);
+        F.wrote_header = true;
+        F.any_frame = true;
+        *F.bitpos = endbit;
+        *F.stream_crc = crc_out;
+        if (F.crcs_out) {
+            size_t o = F.crcs_out->size();
+            F.crcs_out->resize(o + nb);
+            HIPCHK(hipMemcpy(F.crcs_out->data() + o, B.crc, nb * sizeof(u32), hipMemcpyDeviceToHost));
+        }
+        // stats
+        std::vector<u32> hr(nb), hp(nb), hn(nb);
+        HIPCHK(hipMemcpy(hr.data(), B.rounds, nb * sizeof(u32), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(hp.data(), B.periodic, nb * sizeof(u32), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(hn.data(), B.n, nb * sizeof(u32), hipMemcpyDeviceToHost));
+        for (int b = 0; b < nb; b++) {
+            c->st_blocks++;
+            c->st_rounds += hr[b];
+            c->st_rle_bytes += hn[b];
+            c->st_nr += (u64)hn[b] * hr[b];
+            if (hp[b] > 1) c->st_periodic++;
+        }
+    };
+    const int lane0 = c->active_lane;
+    for (u32 b0 = 0, k = 0; b0 < usable; b0 += bsz, k++) {
+        const int lane = two ? (lane0 ^ (int)(k & 1)) : lane0;
+        if (c->active_lane != lane) c->swap_lane();
+        const int nb = (int)std::min<u32>(bsz, usable - b0);
+        u32 max_in = 0;
+        for (int b = 0; b < nb; b++) max_in = std::max(max_in, starts[b0 + b + 1] - starts[b0 + b]);
+        run_rle1_emit(c, d_win, c->w_rs, c->w_starts, b0, nb, max_in, c->w_eagg, c->w_ETPB);
+        run_bwt_n(c, nb, bs);
+        run_mtf(c, nb, bs);
+        run_huffman(c, nb, bs + 1);
+        const Pending cur = {true, lane, nb, trailer_after_last && (b0 + nb == usable)};
+        if (two) {
+            // the previous batch lives in the other lane: pack it now, keep this one pending
+            if (pend.valid) finish(pend);
+            pend = cur;
+        } else {
+            // one lane only (the block estimate can be short of the real count, so several
+            // batches may still be needed): pack before the workspace is reused
+            finish(cur);
+        }
+    }
+    if (pend.valid) finish(pend);
+    if (c->active_lane != lane0) c->swap_lane();
+}
+
 // Compresses blocks of d_in[0..n) into d_out (zeroed by the caller up to out_cap) starting at
 // bit *bitpos.  Only complete blocks are taken unless `final`.  Returns bytes consumed.
 static size_t compress_core(bz2hip_ctx *c, const u8 *d_in, size_t n, int level, u8 *d_out,
                             size_t out_cap, u64 *bitpos, u32 *stream_crc, bool header, bool final,
                             bool trailer = true, std::vector<u32> *crcs_out = nullptr) {
-    const u32 bs = (u32)level * 100000u;
     size_t pos = 0;
-    bool wrote_header = !header;
-    c->st_blocks = c->st_rounds = c->st_rle_bytes = c->st_periodic = 0;
-    c->st_sorted_elems = c->st_nr = c->st_s_elems = 0;
-    c->st_bwt_seconds = 0;
-    c->st_tie_traps = 0;
+    reset_stats(c);
+    FrameState F{d_out, out_cap, bitpos, stream_crc, level, !header, false, crcs_out};
     std::vector<u32> starts;
-    bool any_frame = false;
     while (pos < n) {
         const size_t wlen = std::min<size_t>(n - pos, WMAX);
         const bool last_window = (pos + wlen == n);
-        // Splitting one batch in two costs more than the overlap returns (measured: 221 blocks as
-        // 2 x 111 is 10 % slower), so the second lane is used only when the window needs several
-        // batches anyway.
-        const int est = (int)std::min<size_t>(wlen / (bs - 4) + 1, 1u << 20);
-        const int cap = c->opts.max_batch_blocks > 0 ? c->opts.max_batch_blocks : DEFAULT_BATCH_BLOCKS;
-        static const int lanes_env = getenv("BZ2HIP_LANES") ? atoi(getenv("BZ2HIP_LANES")) : 2;
-        const bool two = est > cap && lanes_env >= 2;
-        // equal batches: ceil(est / number of batches), not cap + remainder
-        const int per = (est + (est + cap - 1) / cap - 1) / ((est + cap - 1) / cap);
-        ensure_batch(c, level, per);
-        if (two) {
-            c->swap_lane();
-            ensure_batch(c, level, per);
-            c->swap_lane();
-        }
-        ensure_window(c, wlen, level);
-        u32 cnt = run_split(c, d_in + pos, (u32)wlen, level, c->w_rs, c->w_P, c->w_agg1, c->w_agg2,
-                            c->w_starts, c->w_maxblocks, starts);
+        const bool two = prepare_window(c, d_in + pos, wlen, level);
+        u32 cnt = run_chain(c, (u32)wlen, level, c->w_rs, c->w_P, c->w_agg2, c->w_starts, c->w_maxblocks, 0,
+                            (u32)wlen, starts);
         // a block that ends at the window end is complete only if this is the final data
         u32 usable = cnt;
         if (!(last_window && final) && cnt > 0 && starts[cnt] == (u32)wlen) usable = cnt - 1;
@@ -291,70 +453,11 @@ static size_t compress_core(bz2hip_ctx *c, const u8 *d_in, size_t n, int level, 
             if (last_window) break; // leave the tail for the next call
             throw HipError(BZ2HIP_E_HIP, "window holds no complete block");
         }
-        // batches of equal size, alternating lanes; pack + frame of batch k (which need the bit
-        // cursor, i.e. host round trips) are issued after the BWT of batch k + 1 has been driven,
-        // so batch k's MTF / Huffman kernels overlap that BWT on the other stream
-        const u32 nbat = (usable + (u32)c->batch.NB - 1) / (u32)c->batch.NB;
-        const u32 bsz = (usable + nbat - 1) / nbat;
-        struct Pending { bool valid; int lane; int nb; bool is_last; } pend = {false, 0, 0, false};
-        auto finish = [&](const Pending &P) {
-            if (c->active_lane != P.lane) c->swap_lane();
-            Batch &B = c->batch;
-            const int nb = P.nb;
-            run_pack(c, nb, bs + 1, d_out, *bitpos, false, 0, out_cap, nullptr);
-            u64 endbit;
-            u32 crc_out;
-            run_frame(c, nb, d_out, level, !wrote_header, P.is_last, *stream_crc, &endbit, &crc_out);
-            wrote_header = true;
-            any_frame = true;
-            *bitpos = endbit;
-            *stream_crc = crc_out;
-            if (crcs_out) {
-                size_t o = crcs_out->size();
-                crcs_out->resize(o + nb);
-                HIPCHK(hipMemcpy(crcs_out->data() + o, B.crc, nb * sizeof(u32), hipMemcpyDeviceToHost));
-            }
-            // stats
-            std::vector<u32> hr(nb), hp(nb), hn(nb);
-            HIPCHK(hipMemcpy(hr.data(), B.rounds, nb * sizeof(u32), hipMemcpyDeviceToHost));
-            HIPCHK(hipMemcpy(hp.data(), B.periodic, nb * sizeof(u32), hipMemcpyDeviceToHost));
-            HIPCHK(hipMemcpy(hn.data(), B.n, nb * sizeof(u32), hipMemcpyDeviceToHost));
-            for (int b = 0; b < nb; b++) {
-                c->st_blocks++;
-                c->st_rounds += hr[b];
-                c->st_rle_bytes += hn[b];
-                c->st_nr += (u64)hn[b] * hr[b];
-                if (hp[b] > 1) c->st_periodic++;
-            }
-        };
-        const int lane0 = c->active_lane;
-        for (u32 b0 = 0, k = 0; b0 < usable; b0 += bsz, k++) {
-            const int lane = two ? (lane0 ^ (int)(k & 1)) : lane0;
-            if (c->active_lane != lane) c->swap_lane();
-            const int nb = (int)std::min<u32>(bsz, usable - b0);
-            u32 max_in = 0;
-            for (int b = 0; b < nb; b++) max_in = std::max(max_in, starts[b0 + b + 1] - starts[b0 + b]);
-            run_rle1_emit(c, d_in + pos, c->w_rs, c->w_starts, b0, nb, max_in, c->w_eagg, c->w_ETPB);
-            run_bwt_n(c, nb, bs);
-            run_mtf(c, nb, bs);
-            run_huffman(c, nb, bs + 1);
-            const Pending cur = {true, lane, nb, final && trailer && last_window && (b0 + nb == usable)};
-            if (two) {
-                // the previous batch lives in the other lane: pack it now, keep this one pending
-                if (pend.valid) finish(pend);
-                pend = cur;
-            } else {
-                // one lane only (the block estimate can be short of the real count, so several
-                // batches may still be needed): pack before the workspace is reused
-                finish(cur);
-            }
-        }
-        if (pend.valid) finish(pend);
-        if (c->active_lane != lane0) c->swap_lane();
+        compress_window_blocks(c, d_in + pos, starts, usable, two, final && trailer && last_window, F);
         pos += starts[usable];
         if (usable < cnt && last_window) break;
     }
-    if (final && trailer && !any_frame) {
+    if (final && trailer && !F.any_frame) {
         // empty input (or nothing left): header and/or trailer only
         ensure_batch(c, level, 1);
         u64 bp = *bitpos;
@@ -362,14 +465,14 @@ static size_t compress_core(bz2hip_ctx *c, const u8 *d_in, size_t n, int level, 
         HIPCHK(hipStreamSynchronize(c->stream));
         u64 endbit;
         u32 crc_out;
-        run_frame(c, 0, d_out, level, !wrote_header, true, *stream_crc, &endbit, &crc_out);
+        run_frame(c, 0, d_out, level, !F.wrote_header, true, *stream_crc, &endbit, &crc_out);
         *bitpos = endbit;
         *stream_crc = crc_out;
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipStreamSynchronize(c->stream_other));
     if (c->profile) c->prof_collect();
-    if (getenv("BZ2HIP_DEBUG"))
+    if (c->debug)
         fprintf(stderr, "[bz2hip] blocks=%llu rle_bytes=%llu rounds_sum=%llu S-elems=%llu radix-elem-passes=%llu periodic=%llu\n",
                 (unsigned long long)c->st_blocks, (unsigned long long)c->st_rle_bytes,
                 (unsigned long long)c->st_rounds, (unsigned long long)c->st_s_elems,
@@ -390,6 +493,80 @@ extern "C" int bz2hip_compress_device(bz2hip_ctx *c, const void *d_in, size_t n,
         u32 scrc = 0;
         compress_core(c, (const u8 *)d_in, n, level, (u8 *)d_out, zlen, &bitpos, &scrc, true, true);
         *out_len = (size_t)((bitpos + 7) / 8);
+        return BZ2HIP_OK;
+    });
+}
+
+// ------------------------------------------------------------------ sharding one stream
+// The K1 scan of a shard does not depend on where its first block starts, so every GPU scans its
+// slice at once; only the block chain is serial across shards (a few dependent loads per block),
+// and what crosses from one shard to the next is a single offset.
+extern "C" int bz2hip_shard_scan(bz2hip_ctx *c, const void *d_in, size_t avail, int level) {
+    return guarded(c, [&]() -> int {
+        if (level < 1 || level > 9) return fail(c, BZ2HIP_E_PARAM, "Invalid BZip2 block size");
+        if (avail && !d_in) return fail(c, BZ2HIP_E_PARAM, "null pointer");
+        if (avail > WMAX) return fail(c, BZ2HIP_E_PARAM, "shard larger than one window (1 GiB): cut it in sub-shards");
+        reset_stats(c);
+        c->sh_in = (const u8 *)d_in;
+        c->sh_avail = avail;
+        c->sh_level = level;
+        c->sh_usable = 0;
+        c->sh_starts.clear();
+        c->sh_two = avail ? prepare_window(c, c->sh_in, avail, level) : false;
+        c->sh_state = 1;
+        return BZ2HIP_OK;
+    });
+}
+
+extern "C" int bz2hip_shard_chain(bz2hip_ctx *c, uint64_t first, uint64_t limit, int final,
+                                  uint32_t *n_blocks, uint64_t *next) {
+    return guarded(c, [&]() -> int {
+        if (!n_blocks || !next) return fail(c, BZ2HIP_E_PARAM, "null pointer");
+        if (c->sh_state < 1) return fail(c, BZ2HIP_E_STATE, "bz2hip_shard_scan has not run");
+        if (first > c->sh_avail) return fail(c, BZ2HIP_E_PARAM, "first block start beyond the shard's data");
+        if (limit > c->sh_avail) limit = c->sh_avail;
+        c->sh_usable = 0;
+        c->sh_starts.assign(1, (u32)first);
+        *n_blocks = 0;
+        *next = first;
+        c->sh_state = 2;
+        if (first >= limit) return BZ2HIP_OK; // the previous shard's last block swallowed this one
+        u32 cnt = run_chain(c, (u32)c->sh_avail, c->sh_level, c->w_rs, c->w_P, c->w_agg2, c->w_starts,
+                            c->w_maxblocks, (u32)first, (u32)limit, c->sh_starts);
+        // a block that runs into the end of the data is complete only if the stream ends there
+        u32 usable = cnt;
+        if (!final && cnt > 0 && c->sh_starts[cnt] == (u32)c->sh_avail) usable = cnt - 1;
+        c->sh_usable = usable;
+        *n_blocks = usable;
+        *next = c->sh_starts[usable];
+        return BZ2HIP_OK;
+    });
+}
+
+extern "C" int bz2hip_shard_compress(bz2hip_ctx *c, void *d_out, size_t cap, uint64_t *nbits,
+                                     uint32_t *crcs, uint32_t max_blocks, uint32_t *n_blocks) {
+    return guarded(c, [&]() -> int {
+        if (!d_out || !nbits || !crcs || !n_blocks) return fail(c, BZ2HIP_E_PARAM, "null pointer");
+        if (((uintptr_t)d_out & 3) != 0) return fail(c, BZ2HIP_E_PARAM, "d_out must be 4-byte aligned");
+        if (c->sh_state < 2) return fail(c, BZ2HIP_E_STATE, "bz2hip_shard_chain has not run");
+        if (c->sh_usable > max_blocks) return fail(c, BZ2HIP_E_CAP, "more blocks than max_blocks");
+        if (cap < 64) return fail(c, BZ2HIP_E_CAP, "output buffer too small");
+        const u32 usable = c->sh_usable;
+        const size_t in_bytes = usable ? (size_t)(c->sh_starts[usable] - c->sh_starts[0]) : 0;
+        size_t zlen = std::min(cap, bz2hip_compress_bound(in_bytes)) & ~(size_t)3;
+        HIPCHK(hipMemsetAsync(d_out, 0, zlen, c->stream));
+        u64 bitpos = 0;
+        u32 scrc = 0;
+        std::vector<u32> cr;
+        FrameState F{(u8 *)d_out, zlen, &bitpos, &scrc, c->sh_level, true, false, &cr};
+        if (usable) compress_window_blocks(c, c->sh_in, c->sh_starts, usable, c->sh_two, false, F);
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream_other));
+        if (c->profile) c->prof_collect();
+        for (size_t i = 0; i < cr.size(); i++) crcs[i] = cr[i];
+        *n_blocks = (uint32_t)cr.size();
+        *nbits = bitpos;
+        c->sh_state = 1; // the scan stays valid: another chain + compress may follow
         return BZ2HIP_OK;
     });
 }
@@ -485,6 +662,57 @@ extern "C" int bz2hip_compress_blocks(bz2hip_ctx *c, const uint8_t *in, size_t n
     });
 }
 
+// Appends nbits bits of src (MSB first) at bit *pos of out.  The bytes out[*pos/8 + 1 ...] are
+// overwritten; the byte that holds bit *pos keeps its high (*pos & 7) bits.  64 bits per step.
+static void append_bits(u8 *out, u64 *pos, const u8 *src, u64 nbits) {
+    if (!nbits) return;
+    u8 *p = out + (*pos >> 3);
+    const int sh = (int)(*pos & 7);
+    const u64 full = nbits >> 3;
+    const int rem = (int)(nbits & 7);
+    if (sh == 0) {
+        memcpy(p, src, full);
+        if (rem) p[full] = (u8)(src[full] & (0xff00u >> rem));
+    } else {
+        u64 carry = (u64)(p[0] >> (8 - sh)); // the sh pending bits, low-aligned
+        u64 k = 0;
+        for (; k + 8 <= full; k += 8) {
+            u64 v;
+            memcpy(&v, src + k, 8);
+            v = __builtin_bswap64(v);
+            u64 o = __builtin_bswap64((carry << (64 - sh)) | (v >> sh));
+            memcpy(p + k, &o, 8);
+            carry = v & ((1ull << sh) - 1ull);
+        }
+        // tail: bytes, then the last partial byte
+        u32 acc = (u32)carry;
+        int nb = sh;
+        u8 *q = p + k;
+        for (; k < full; k++) {
+            acc = (acc << 8) | src[k];
+            *q++ = (u8)(acc >> nb);
+            acc &= (1u << nb) - 1u;
+        }
+        if (rem) {
+            acc = (acc << rem) | (u32)(src[full] >> (8 - rem));
+            nb += rem;
+            if (nb >= 8) {
+                *q++ = (u8)(acc >> (nb - 8));
+                nb -= 8;
+                acc &= (1u << nb) - 1u;
+            }
+        }
+        if (nb > 0) *q = (u8)(acc << (8 - nb));
+    }
+    *pos += nbits;
+}
+
+static void append_value(u8 *out, u64 *pos, int cnt, u32 v) {
+    const u32 w = v << (32 - cnt); // the cnt low bits of v, left-aligned
+    const u8 be[4] = {(u8)(w >> 24), (u8)(w >> 16), (u8)(w >> 8), (u8)w};
+    append_bits(out, pos, be, (u64)cnt);
+}
+
 // Host-side ordered concatenation of block segments into one stream (K8 across GPUs):
 // S/BZip2OutputStream.swift:139 (CRC fold), :154-157 (trailer), :181-184 (header),
 // S/BZip2BitOutputStream.swift:116-120 (zero pad).  Pure host code, no context needed.
@@ -492,32 +720,65 @@ extern "C" int bz2hip_stitch(int level, uint32_t nseg, const uint8_t *const *seg
                              const uint64_t *seg_nbits, const uint32_t *const *seg_crcs,
                              const uint32_t *seg_ncrc, uint8_t *out, size_t cap, size_t *out_len) {
     if (level < 1 || level > 9 || !out || !out_len) return BZ2HIP_E_PARAM;
+    if (nseg && (!seg_bits || !seg_nbits || !seg_crcs || !seg_ncrc)) return BZ2HIP_E_PARAM;
     u64 total = 32 + 80;
     for (u32 i = 0; i < nseg; i++) total += seg_nbits[i];
     if ((total + 7) / 8 > cap) return BZ2HIP_E_CAP;
-    u8 *p = out;
-    u64 acc = 0;
-    int nb = 0;
-    auto put = [&](int cnt, u32 v) {
-        acc = (acc << cnt) | (u64)(v & (cnt >= 32 ? 0xffffffffu : ((1u << cnt) - 1u)));
-        nb += cnt;
-        while (nb >= 8) { *p++ = (u8)(acc >> (nb - 8)); nb -= 8; }
-    };
-    put(16, 0x425a); put(8, 0x68); put(8, (u32)('0' + level));
+    u64 pos = 0;
+    out[0] = 0;
+    append_value(out, &pos, 16, 0x425a);
+    append_value(out, &pos, 8, 0x68);
+    append_value(out, &pos, 8, (u32)('0' + level));
     u32 scrc = 0;
     for (u32 i = 0; i < nseg; i++) {
-        const u8 *src = seg_bits[i];
-        u64 full = seg_nbits[i] >> 3;
-        if (nb == 0) { memcpy(p, src, full); p += full; }
-        else for (u64 k = 0; k < full; k++) put(8, src[k]);
-        int rem = (int)(seg_nbits[i] & 7);
-        if (rem) put(rem, (u32)(src[full] >> (8 - rem)));
+        if ((pos & 7) == 0) out[pos >> 3] = 0;
+        append_bits(out, &pos, seg_bits[i], seg_nbits[i]);
         for (u32 k = 0; k < seg_ncrc[i]; k++) scrc = ((scrc << 1) | (scrc >> 31)) ^ seg_crcs[i][k];
     }
-    put(24, 0x177245); put(24, 0x385090); put(16, scrc >> 16); put(16, scrc & 0xffff);
-    if (nb > 0) { *p++ = (u8)(acc << (8 - nb)); nb = 0; }
-    *out_len = (size_t)(p - out);
+    if ((pos & 7) == 0) out[pos >> 3] = 0;
+    append_value(out, &pos, 24, 0x177245);
+    append_value(out, &pos, 24, 0x385090);
+    append_value(out, &pos, 16, scrc >> 16);
+    append_value(out, &pos, 16, scrc & 0xffff);
+    *out_len = (size_t)((pos + 7) >> 3);
     return BZ2HIP_OK;
+}
+
+// The same concatenation with the segments and the stream resident in HBM: every segment is
+// funnel-shifted to its bit offset by a kernel (k8_place), then header and trailer are written.
+void run_place(bz2hip_ctx *c, const u8 *d_src, u64 nbits, u8 *d_out, u64 dst_bit); // k4_huffman.hip
+void run_ends(bz2hip_ctx *c, u8 *d_out, int level, u64 end_bit, u32 scrc);          // k4_huffman.hip
+
+extern "C" int bz2hip_stitch_device(bz2hip_ctx *c, int level, uint32_t nseg,
+                                    const void *const *d_seg_bits, const uint64_t *seg_nbits,
+                                    const uint32_t *const *seg_crcs, const uint32_t *seg_ncrc,
+                                    void *d_out, size_t cap, size_t *out_len) {
+    return guarded(c, [&]() -> int {
+        if (level < 1 || level > 9) return fail(c, BZ2HIP_E_PARAM, "Invalid BZip2 block size");
+        if (!d_out || !out_len) return fail(c, BZ2HIP_E_PARAM, "null pointer");
+        if (nseg && (!d_seg_bits || !seg_nbits || !seg_crcs || !seg_ncrc)) return fail(c, BZ2HIP_E_PARAM, "null pointer");
+        if (((uintptr_t)d_out & 3) != 0) return fail(c, BZ2HIP_E_PARAM, "d_out must be 4-byte aligned");
+        u64 total = 32 + 80;
+        for (u32 i = 0; i < nseg; i++) {
+            if (seg_nbits[i] && (((uintptr_t)d_seg_bits[i]) & 3) != 0)
+                return fail(c, BZ2HIP_E_PARAM, "segments must be 4-byte aligned");
+            total += seg_nbits[i];
+        }
+        const size_t words = (size_t)((total + 31) / 32);
+        if (words * 4 > cap) return fail(c, BZ2HIP_E_CAP, "output buffer too small");
+        HIPCHK(hipMemsetAsync(d_out, 0, words * 4, c->stream));
+        u64 pos = 32;
+        u32 scrc = 0;
+        for (u32 i = 0; i < nseg; i++) {
+            if (seg_nbits[i]) run_place(c, (const u8 *)d_seg_bits[i], seg_nbits[i], (u8 *)d_out, pos);
+            pos += seg_nbits[i];
+            for (u32 k = 0; k < seg_ncrc[i]; k++) scrc = ((scrc << 1) | (scrc >> 31)) ^ seg_crcs[i][k];
+        }
+        run_ends(c, (u8 *)d_out, level, pos, scrc);
+        HIPCHK(hipStreamSynchronize(c->stream));
+        *out_len = (size_t)((pos + 80 + 7) / 8);
+        return BZ2HIP_OK;
+    });
 }
 
 // ------------------------------------------------------------------ streaming

@@ -106,6 +106,16 @@ struct bz2hip_ctx {
     u32 *w_rs = nullptr, *w_P = nullptr, *w_agg1 = nullptr, *w_agg2 = nullptr;
     u32 *w_starts = nullptr, *w_eagg = nullptr;
     u32 *w_cagg = nullptr;   // CRC tile partials (same shape as w_eagg; used on the other stream)
+    void *w_region = nullptr;  // device region holding rs / P / aggregates / starts
+    void *w_eregion = nullptr; // device region holding the emit / CRC tile partials
+    // tuning knobs, read from the environment once in bz2hip_create (experiments only)
+    int lanes = 2;           // BZ2HIP_LANES
+    int debug = 0;           // BZ2HIP_DEBUG
+    u32 plain_mask = 2;      // BZ2HIP_PLAIN
+    u32 r0bits = 40;         // BZ2HIP_R0BITS
+    u32 r0_sweeps = 2;       // BZ2HIP_RSWEEPS
+    bool fixed_ws = false;   // allocation-free call in progress: workspace carved from the static scratch
+    u8 *scratch = nullptr;   // this device's address of the static scratch array (api.hip)
     hipEvent_t crc_done = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr; // S-sort || L-path inside a doubling round
     size_t w_cap = 0;        // window capacity in input bytes
@@ -130,6 +140,13 @@ struct bz2hip_ctx {
     u64 st_s_elems = 0;      // elements sorted by the LDS (S) path, summed over rounds
     u64 st_sorted_elems = 0; // sum over radix passes of elements moved
     u64 st_nr = 0;           // sum over blocks of n_b * doubling rounds_b
+    // sharding state (bz2hip_shard_scan / _chain / _compress)
+    const u8 *sh_in = nullptr;
+    size_t sh_avail = 0;
+    int sh_level = 0, sh_state = 0;
+    bool sh_two = false;
+    u32 sh_usable = 0;
+    std::vector<u32> sh_starts;
     // streaming state
     int s_level = 0;
     bool s_open = false, s_finished = false;
@@ -204,6 +221,9 @@ void run_frame(bz2hip_ctx *c, int nb, u8 *d_out, int level, bool header, bool tr
                u64 *end_bit, u32 *crc_out);                            // k4_huffman.hip
 // K1 (k1_rle1.hip)
 void k1_init_tables(bz2hip_ctx *c);
+void run_scan(bz2hip_ctx *c, const u8 *d_in, u32 n, u32 *d_rs, u32 *d_P, u32 *d_agg1, u32 *d_agg2);
+u32 run_chain(bz2hip_ctx *c, u32 n, int level, const u32 *d_rs, const u32 *d_P, const u32 *d_agg2,
+              u32 *d_starts, u32 max_blocks, u32 s0, u32 stop, std::vector<u32> &h_starts);
 u32 run_split(bz2hip_ctx *c, const u8 *d_in, u32 n, int level, u32 *d_rs, u32 *d_P, u32 *d_agg1,
               u32 *d_agg2, u32 *d_starts, u32 max_blocks, std::vector<u32> &h_starts);
 void run_rle1_emit(bz2hip_ctx *c, const u8 *d_in, const u32 *d_rs, const u32 *d_starts, u32 b0,

@@ -235,15 +235,18 @@ __device__ bool wave_bracket(const ARR arr, u32 lo, u32 hi, u32 thr, u32 *nlo, u
 // The chain is pure memory latency (each block's start is the previous block's end), so a block
 // costs as few dependent loads as possible: the run-end probe also fetches the prefix it will need,
 // and the search first tries a narrow bracket around "as long as the previous block".
+// The chain begins at s0 (a block start; a run that straddles s0 is cut there, so nothing before
+// s0 matters) and takes blocks whose start lies below `stop` (sharding: the next shard continues
+// from starts[count]).
 __global__ __launch_bounds__(64) void k1_split(const u32 *__restrict__ rs,
                                                const u32 *__restrict__ Ploc,
                                                const u32 *__restrict__ agg_c, u32 n, u32 block_size,
                                                u32 max_blocks, u32 *__restrict__ starts,
-                                               u32 *__restrict__ count_out) {
+                                               u32 *__restrict__ count_out, u32 s0, u32 stop) {
     const u32 limit = block_size - 6;
     const PrefixArr P{Ploc, agg_c};
-    u32 s = 0, cnt = 0, plen = 0, perr = 0;
-    while (s < n && cnt < max_blocks) {
+    u32 s = s0, cnt = 0, plen = 0, perr = 0;
+    while (s < n && s < stop && cnt < max_blocks) {
         if (lane_id() == 0) starts[cnt] = s;
         // end of the run containing s: almost always within the next 64 bytes; the same step
         // fetches P(idx + 1), which is P(re0 + 1) for the lane that finds the run end
@@ -545,29 +548,33 @@ void k1_init_tables(bz2hip_ctx *c) {
     if (c->device >= 0 && c->device < 64) g_crc_tables_ready[c->device] = true;
 }
 
-// Scan a window of input: fills rs[0..n], P[0..n] and the block starts (device array).
-// Returns the number of blocks found (<= max_blocks); h_starts receives count+1 offsets.
-u32 run_split(bz2hip_ctx *c, const u8 *d_in, u32 n, int level, u32 *d_rs, u32 *d_P, u32 *d_agg1,
-              u32 *d_agg2, u32 *d_starts, u32 max_blocks, std::vector<u32> &h_starts) {
+// Scan a window of input: fills rs[0..n], P[0..n] (asynchronous; independent of where blocks start).
+void run_scan(bz2hip_ctx *c, const u8 *d_in, u32 n, u32 *d_rs, u32 *d_P, u32 *d_agg1, u32 *d_agg2) {
     Batch &B = c->batch;
     const u32 tiles = (n + K1_TILE - 1) / K1_TILE;
-    {
-        ProfScope ps(c, P_RLE1_SCAN, 0);
-        k1_heads_p1<<<tiles, 256, 0, c->stream>>>(d_in, n, d_agg1);
-        KCHECK();
-        k1_scan_tiles<true><<<1, 1024, 0, c->stream>>>(d_agg1, tiles, nullptr);
-        KCHECK();
-        k1_runs<<<tiles, 256, 0, c->stream>>>(d_in, n, d_agg1, d_rs, d_agg2, d_P);
-        KCHECK();
-        k1_scan_tiles<false><<<1, 1024, 0, c->stream>>>(d_agg2, tiles, B.ctl + 8);
-        KCHECK();
-        k1_sentinels<<<1, 64, 0, c->stream>>>(d_rs, d_P, d_agg2, n, B.ctl + 8);
-        KCHECK();
-    }
+    ProfScope ps(c, P_RLE1_SCAN, 0);
+    k1_heads_p1<<<tiles, 256, 0, c->stream>>>(d_in, n, d_agg1);
+    KCHECK();
+    k1_scan_tiles<true><<<1, 1024, 0, c->stream>>>(d_agg1, tiles, nullptr);
+    KCHECK();
+    k1_runs<<<tiles, 256, 0, c->stream>>>(d_in, n, d_agg1, d_rs, d_agg2, d_P);
+    KCHECK();
+    k1_scan_tiles<false><<<1, 1024, 0, c->stream>>>(d_agg2, tiles, B.ctl + 8);
+    KCHECK();
+    k1_sentinels<<<1, 64, 0, c->stream>>>(d_rs, d_P, d_agg2, n, B.ctl + 8);
+    KCHECK();
+}
+
+// The serial block chain over a scanned window, from block start s0, for blocks that start below
+// `stop`.  Returns the number of blocks found (<= max_blocks); h_starts receives count+1 offsets
+// (h_starts[count] = end of the last block = start of the next).
+u32 run_chain(bz2hip_ctx *c, u32 n, int level, const u32 *d_rs, const u32 *d_P, const u32 *d_agg2,
+              u32 *d_starts, u32 max_blocks, u32 s0, u32 stop, std::vector<u32> &h_starts) {
+    Batch &B = c->batch;
     {
         ProfScope ps(c, P_RLE1_SPLIT, 0);
         k1_split<<<1, 64, 0, c->stream>>>(d_rs, d_P, d_agg2, n, (u32)level * 100000u, max_blocks, d_starts,
-                                          B.ctl + 9);
+                                          B.ctl + 9, s0, stop);
         KCHECK();
     }
     u32 cnt = 0;
@@ -578,6 +585,12 @@ u32 run_split(bz2hip_ctx *c, const u8 *d_in, u32 n, int level, u32 *d_rs, u32 *d
                           c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return cnt;
+}
+
+u32 run_split(bz2hip_ctx *c, const u8 *d_in, u32 n, int level, u32 *d_rs, u32 *d_P, u32 *d_agg1,
+              u32 *d_agg2, u32 *d_starts, u32 max_blocks, std::vector<u32> &h_starts) {
+    run_scan(c, d_in, n, d_rs, d_P, d_agg1, d_agg2);
+    return run_chain(c, n, level, d_rs, d_P, d_agg2, d_starts, max_blocks, 0, n, h_starts);
 }
 
 // CRC of nb byte ranges [starts[b], starts[b+1]) of d_data (the decoder's use of the CRC kernels)
@@ -600,7 +613,6 @@ void run_rle1_emit(bz2hip_ctx *c, const u8 *d_in, const u32 *d_rs, const u32 *d_
     dim3 grid(tiles, nb);
     // The block CRCs depend only on the input and the block starts: they run on the other stream,
     // next to the emit scan; this stream waits for them before anything that follows.
-    if (!c->crc_done) HIPCHK(hipEventCreateWithFlags(&c->crc_done, hipEventDisableTiming));
     {
         k1_crc_p1<<<grid, 256, 0, c->stream_other>>>(d_in, d_starts + b0, c->w_cagg, ETPB);
         KCHECK();

@@ -1516,10 +1516,10 @@ void run_present(bz2hip_ctx *c, int nb, u32 maxn) {
 }
 
 // ------------------------------------------------------------------ driver
-// bit set = plain (x-fastest) mapping for that kernel family; default: S-sort only
-static u32 g_plain_mask = 2;
-static u32 g_r0bits = 40; // key bits of the first sort (multiple of 8)
-static inline u32 nbarg(u32 nb, u32 bit) { return (g_plain_mask & bit) ? (nb | 0x80000000u) : nb; }
+// tuning lives in the context (read from the environment once, in bz2hip_create):
+// plain_mask: bit set = plain (x-fastest) mapping for that kernel family (default: S-sort only);
+// r0bits: key bits of the first sort (multiple of 8)
+#define nbarg(nb, bit) ((c->plain_mask & (bit)) ? ((u32)(nb) | 0x80000000u) : (u32)(nb))
 
 // `from_T`: the first pass builds the round-0 keys from the block bytes instead of reading `a`
 static void radix_sort5(bz2hip_ctx *c, int nb, u32 maxcnt, const u32 *cntArr, u64 *a, u64 *bbuf,
@@ -1534,10 +1534,10 @@ static void radix_sort5(bz2hip_ctx *c, int nb, u32 maxcnt, const u32 *cntArr, u6
             ProfScope ps(c, P_RADIX_HIST);
             if (ft)
                 k2_radix_hist<true><<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(
-                    kin, cntArr, B.state, B.tilehist, B.S, B.TPB, shift, tiles, nbarg(nb, 8), B.T, B.present, g_r0bits);
+                    kin, cntArr, B.state, B.tilehist, B.S, B.TPB, shift, tiles, nbarg(nb, 8), B.T, B.present, c->r0bits);
             else
                 k2_radix_hist<false><<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(
-                    kin, cntArr, B.state, B.tilehist, B.S, B.TPB, shift, tiles, nbarg(nb, 8), B.T, B.present, g_r0bits);
+                    kin, cntArr, B.state, B.tilehist, B.S, B.TPB, shift, tiles, nbarg(nb, 8), B.T, B.present, c->r0bits);
             KCHECK();
         }
         {
@@ -1550,11 +1550,11 @@ static void radix_sort5(bz2hip_ctx *c, int nb, u32 maxcnt, const u32 *cntArr, u6
             if (ft)
                 k2_radix_scatter<true><<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(
                     kin, kout, cntArr, B.state, B.tilehist, B.digitbase, B.S, B.TPB, shift, tiles, nbarg(nb, 8),
-                    B.T, B.present, g_r0bits);
+                    B.T, B.present, c->r0bits);
             else
                 k2_radix_scatter<false><<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(
                     kin, kout, cntArr, B.state, B.tilehist, B.digitbase, B.S, B.TPB, shift, tiles, nbarg(nb, 8),
-                    B.T, B.present, g_r0bits);
+                    B.T, B.present, c->r0bits);
             KCHECK();
         }
         std::swap(kin, kout);
@@ -1574,12 +1574,7 @@ static void lrerank(bz2hip_ctx *c, int nb, u32 maxcnt, const u32 *cntArr, u32 wa
     k2_lrerank_p2<<<nb, 256, 0, c->stream>>>(cntArr, B.state, want, B.tileagg, B.mLn, B.leftg,
                                              MODE == MODE_FINAL ? 1 : 0, B.TPB);
     KCHECK();
-    static const u32 r0_sweeps = [] {
-        const char *e = getenv("BZ2HIP_RSWEEPS");
-        int v = e ? atoi(e) : 2;
-        return (u32)(v < 1 ? 1 : v > 16 ? 16 : v);
-    }();
-    const u32 nsw = (MODE == MODE_ROUND0) ? r0_sweeps : 1u;
+    const u32 nsw = (MODE == MODE_ROUND0) ? c->r0_sweeps : 1u;
     k2_lrerank_p3<MODE><<<xcd_grid(tiles * nsw, nb), RT_THREADS, 0, c->stream>>>(
         sorted, lout, B.slA, B.slB, B.par, cntArr, B.state, want, B.tileagg, B.rank, B.T, B.bwt, B.n,
         B.mSn, B.S, B.TPB, tiles, nbarg(nb, 4), nsw);
@@ -1591,15 +1586,13 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
     Batch &B = c->batch;
     if (nb == 0 || maxn == 0) return;
     const auto t_begin = std::chrono::steady_clock::now();
-    if (const char *pm = getenv("BZ2HIP_PLAIN")) g_plain_mask = (u32)atoi(pm);
-    if (const char *pm = getenv("BZ2HIP_R0BITS")) g_r0bits = (u32)atoi(pm);
     const u32 tiles = (maxn + RTILE - 1) / RTILE;
     const int cb = (nb + 255) / 256;
     HIPCHK(hipMemsetAsync(B.ctl, 0, 16 * sizeof(u32), c->stream));
     k2_reset<<<cb, 256, 0, c->stream>>>(B.n, B.present, B.mS, B.mL, B.mSn, B.mLn, B.hcur, B.huse,
-                                        B.state, B.par, B.rounds, B.leftg, B.periodic, B.ctl, nb, g_r0bits);
+                                        B.state, B.par, B.rounds, B.leftg, B.periodic, B.ctl, nb, c->r0bits);
     KCHECK();
-    const int r0p = (int)g_r0bits / 8;
+    const int r0p = (int)c->r0bits / 8;
     // The first pass reads the block bytes, so the keys are first written by its scatter.  The
     // sorted keys must end in keyB (the L-list is rebuilt into keyA): with an odd pass count the
     // passes go (T) -> keyB -> keyA -> ... -> keyB, so the "input" of pass 0 is nominally keyA.
@@ -1634,7 +1627,7 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
         finL = hc[6];
         if (!hc[0]) break;
         const u32 maxS = hc[1], maxL = hc[2];
-        if (getenv("BZ2HIP_DEBUG") && getenv("BZ2HIP_DEBUG")[0] == '2')
+        if (c->debug >= 2)
             fprintf(stderr, "[bz2hip] round: maxS=%u maxL=%u sumS=%u sumL=%u\n", maxS, maxL, hc[7], hc[3]);
         c->st_sorted_elems += (u64)hc[3] * 5;
         c->st_s_elems += hc[7];
@@ -1657,8 +1650,6 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
         // other stream.
         const bool fork = maxS && maxL;
         if (fork) {
-            if (!c->ev_fork) HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-            if (!c->ev_join) HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
             HIPCHK(hipEventRecord(c->ev_fork, c->stream));
             HIPCHK(hipStreamWaitEvent(c->stream_other, c->ev_fork, 0));
         }

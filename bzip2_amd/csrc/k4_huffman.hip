@@ -647,6 +647,60 @@ __global__ void k8_frame(const u32 *__restrict__ crc, const u64 *__restrict__ bi
     ctl_out[2] = sc;
 }
 
+// ------------------------------------------------------------------ segment placement (K8 across shards)
+// Copies nbits bits of src (bit 0 = MSB of byte 0; 4-byte aligned) to stream bit `dst` of out: one
+// 32-bit destination word per thread, two source words funnel-shifted.  Words shared with the
+// neighbouring segments are OR-ed in (out is zeroed before), inner words are plain stores.
+__global__ __launch_bounds__(256) void k8_place(const u32 *__restrict__ src, u64 nbits,
+                                                u32 *__restrict__ out, u64 dst) {
+    const u64 w0 = dst >> 5, w1 = (dst + nbits - 1) >> 5;
+    const u64 j = (u64)blockIdx.x * 256u + threadIdx.x; // destination word w0 + j
+    const u64 w = w0 + j;
+    if (w > w1) return;
+    const int sh = (int)(dst & 31);
+    const u64 nsrcw = (nbits + 31) >> 5;
+    const u32 a = (sh && j > 0) ? __builtin_bswap32(src[j - 1]) : 0u;
+    const u32 b = (j < nsrcw) ? __builtin_bswap32(src[j]) : 0u;
+    u32 v = sh ? ((a << (32 - sh)) | (b >> sh)) : b;
+    // keep the stream bits [lo, hi) of this word
+    const u64 lo = (w << 5) > dst ? (w << 5) : dst;
+    const u64 end = dst + nbits;
+    const u64 hi = ((w + 1) << 5) < end ? ((w + 1) << 5) : end;
+    const u32 mask = (0xffffffffu >> (u32)(lo & 31)) & (0xffffffffu << (31u - (u32)((hi - 1) & 31)));
+    v &= mask;
+    if (w == w0 || w == w1) {
+        if (v) atomicOr(&out[w], __builtin_bswap32(v));
+    } else {
+        out[w] = __builtin_bswap32(v);
+    }
+}
+
+// stream header at bit 0, end marker + stream CRC at end_bit (S/BZip2OutputStream.swift:154-157,181-184)
+__global__ void k8_ends(u32 *__restrict__ out, int level, u64 end_bit, u32 scrc) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    put_bits(out, 0, 16, 0x425a);
+    put_bits(out, 16, 8, 0x68);
+    put_bits(out, 24, 8, (u32)('0' + level));
+    u64 p = end_bit;
+    put_bits(out, p, 24, 0x177245); p += 24;
+    put_bits(out, p, 24, 0x385090); p += 24;
+    put_bits(out, p, 16, scrc >> 16); p += 16;
+    put_bits(out, p, 16, scrc & 0xffff);
+}
+
+void run_place(bz2hip_ctx *c, const u8 *d_src, u64 nbits, u8 *d_out, u64 dst_bit) {
+    const u64 words = ((dst_bit + nbits - 1) >> 5) - (dst_bit >> 5) + 1;
+    ProfScope ps(c, P_FINAL);
+    k8_place<<<(unsigned)((words + 255) / 256), 256, 0, c->stream>>>((const u32 *)d_src, nbits, (u32 *)d_out, dst_bit);
+    KCHECK();
+}
+
+void run_ends(bz2hip_ctx *c, u8 *d_out, int level, u64 end_bit, u32 scrc) {
+    ProfScope ps(c, P_FINAL);
+    k8_ends<<<1, 64, 0, c->stream>>>((u32 *)d_out, level, end_bit, scrc);
+    KCHECK();
+}
+
 // ------------------------------------------------------------------ drivers
 void run_huffman(bz2hip_ctx *c, int nb, u32 maxmtf) {
     Batch &B = c->batch;

@@ -94,6 +94,36 @@ int bz2hip_compress_blocks(bz2hip_ctx *ctx, const uint8_t *in, size_t n, int lev
                            size_t cap, uint64_t *nbits, uint32_t *crcs, uint32_t max_blocks,
                            uint32_t *n_blocks);
 
+/* ---- one stream sharded over several GPUs / processes -----------------------------------
+ * No counterpart in the reference (single-threaded, S/BZip2OutputStream.swift:29); the block
+ * boundaries are those of BZip2BlockCompressor.write (S/BZip2BlockCompressor.swift:198-227), and
+ * what the shards produce is concatenated as closeBlock / finish would (S/BZip2OutputStream.swift:
+ * 131-141,149-161).  A shard is a slice d_in[0..avail) of the stream: the bytes of its nominal
+ * range [.., limit) plus lookahead, because its last block may end beyond `limit`.
+ *   bz2hip_shard_scan      run-length scan of the slice (asynchronous; does not depend on where
+ *                          blocks start, so every shard scans at once); avail <= 1 GiB
+ *   bz2hip_shard_chain     the serial block chain: from `first` (a block start, slice-relative;
+ *                          0 for the first shard, the previous shard's *next otherwise) it takes
+ *                          the blocks that start below `limit`.  *next = slice-relative start of
+ *                          the first block NOT taken = where the next shard continues.  final != 0:
+ *                          the stream ends at d_in + avail.  A last block that runs into the end
+ *                          of the slice without `final` is not taken (*next < limit then: scan
+ *                          again with more lookahead).
+ *   bz2hip_shard_compress  compresses the blocks of the last chain into bit-abutted blocks from
+ *                          bit 0 of d_out (no stream header / trailer), like
+ *                          bz2hip_compress_blocks_device. */
+int bz2hip_shard_scan(bz2hip_ctx *ctx, const void *d_in, size_t avail, int level);
+int bz2hip_shard_chain(bz2hip_ctx *ctx, uint64_t first, uint64_t limit, int final,
+                       uint32_t *n_blocks, uint64_t *next);
+int bz2hip_shard_compress(bz2hip_ctx *ctx, void *d_out, size_t cap, uint64_t *nbits,
+                          uint32_t *crcs, uint32_t max_blocks, uint32_t *n_blocks);
+
+/* bz2hip_stitch with the segments and the stream resident in HBM (device pointers in the host
+ * array d_seg_bits, 4-byte aligned; CRCs on the host): K8 across shards on one GPU. */
+int bz2hip_stitch_device(bz2hip_ctx *ctx, int level, uint32_t nseg, const void *const *d_seg_bits,
+                         const uint64_t *seg_nbits, const uint32_t *const *seg_crcs,
+                         const uint32_t *seg_ncrc, void *d_out, size_t cap, size_t *out_len);
+
 /* Ordered concatenation of block segments (from bz2hip_compress_blocks*) into one stream: the
  * sequential part of BZip2OutputStream -- header :181-184, bit-abutted blocks, CRC fold :139,
  * end marker + stream CRC + zero pad :154-157 (S/BZip2OutputStream.swift).  Host only. */

@@ -258,24 +258,84 @@ def test_streaming_api(ctx, orc):
     assert ctx.stream_read() == bytes.fromhex("425a683917724538509000000000")
 
 
-def test_sharded_engine_on_gpu(ctx, orc):
-    # the multi-GPU path with the real engine, both "ranks" run here one after the other
+def _sharded_on_one_gpu(ctx, data, level, world, lookahead=None, device_stitch=False):
+    """every "rank" of the multi-GPU path, one after the other on this GPU, through the C ABI"""
+    import torch
     from bzip2_amd import parallel
-    d = corpus.mixed(5, 77, seg_bytes=500000)
+    from bzip2_amd._lib import stitch
+    hop = {}
+    segs = []
+    keep = []
+    for r in range(world):
+        eng = parallel.GpuShardEngine(ctx)
+        eng.bind(data)
+        if device_stitch:
+            eng.compress = eng.compress_device
+            eng.empty = lambda: (torch.zeros(4, dtype=torch.uint8, device="cuda"), 0, np.zeros(0, dtype=np.uint32))
+        seg = parallel.run_rank(eng, level, r, world, data.size, lambda r=r: hop[r],
+                                lambda v, r=r: hop.__setitem__(r + 1, v), lookahead=lookahead)
+        if device_stitch:
+            seg = (seg[0][: (seg[1] + 7) // 8 + 8].clone(), seg[1], seg[2])
+            keep.append(seg[0])
+        segs.append(seg)
+    if not device_stitch:
+        return stitch(level, segs)
+    total = sum(s[1] for s in segs) // 8 + 64
+    d_out = torch.empty(total, dtype=torch.uint8, device="cuda")
+    n = ctx.stitch_device(level, [(s[0].data_ptr(), s[1], s[2]) for s in segs], d_out.data_ptr(), total)
+    return d_out[:n].cpu().numpy().tobytes()
+
+
+def test_sharded_engine_on_gpu(ctx, orc):
+    # the multi-GPU path with the real engine, all "ranks" run here one after the other
+    d = np.concatenate((corpus.mixed(5, 77, seg_bytes=500000), np.zeros(3_000_000, dtype=np.uint8),
+                        corpus.mixed(3, 78, seg_bytes=400000)))
     want, _ = orc.compress(d, 3)
-    assert parallel.compress_sharded(d, 3, ctx) == want
-    held = {}
+    for world in (1, 2, 3, 8):
+        assert _sharded_on_one_gpu(ctx, d, 3, world) == want, world
+        assert _sharded_on_one_gpu(ctx, d, 3, world, lookahead=20000, device_stitch=True) == want, world
+    tiny = d[:777]
+    assert _sharded_on_one_gpu(ctx, tiny, 9, 4, device_stitch=True) == orc.compress(tiny, 9)[0]
+    empty = d[:0]
+    assert _sharded_on_one_gpu(ctx, empty, 9, 2) == bytes.fromhex("425a683917724538509000000000")
+    assert _sharded_on_one_gpu(ctx, empty, 9, 2, device_stitch=True) == bytes.fromhex("425a683917724538509000000000")
 
-    def make_gather(r):
-        def gather(seg):
-            held[r] = seg
-            return [held[k] for k in range(3)] if r == 0 else None
-        return gather
 
-    out = None
-    for r in (2, 1, 0):  # rank 0 last, once every shard exists
-        out = parallel.compress_sharded(d, 3, ctx, rank=r, world=3, gather=make_gather(r))
-    assert out == want
+def test_stream1g_config4(ctx, orc):
+    """BASELINE config 4: the 1 GiB `stream1g` corpus as ONE stream at -9, whole and as 2 / 4 / 8
+    contiguous shards (run one after the other on this GPU) with ordered concatenation: all four
+    streams are byte-identical, their beginning equals the oracle's stream of the same blocks, and
+    the GPU decoder returns the input."""
+    import hashlib
+    import torch
+    d = corpus.mixed(1024, corpus.STREAM1G_SEED)
+    assert d.size == 1 << 30
+    d_in = torch.from_numpy(d).to("cuda")
+    cap = ctx.L.bz2hip_compress_bound(d.size)
+    d_out = torch.empty(cap + 64, dtype=torch.uint8, device="cuda")
+    n1 = ctx.compress_device(d_in.data_ptr(), d.size, 9, d_out.data_ptr(), cap)
+    whole = d_out[:n1].cpu().numpy().tobytes()
+    h1 = hashlib.sha256(whole).hexdigest()
+    blocks = ctx.last_stats()["blocks"]
+    assert blocks > 800
+    for world in (2, 4, 8):
+        got = _sharded_on_one_gpu(ctx, d, 9, world, device_stitch=True)
+        assert len(got) == n1 and hashlib.sha256(got).hexdigest() == h1, world
+    # the host stitch gives the same bytes as the device stitch
+    assert _sharded_on_one_gpu(ctx, d, 9, 4) == whole
+    # the first ~24 MiB against the oracle: cut at a block boundary k, the oracle's stream of
+    # d[:k] agrees with ours up to its trailer
+    ctx.shard_scan(d_in.data_ptr(), 32 << 20, 9)
+    nb, k = ctx.shard_chain(0, 24 << 20, False)
+    assert nb >= 20 and k >= (24 << 20)
+    want, onb = orc.compress(d[:k], 9, threads=8)
+    assert onb == nb
+    assert whole[: len(want) - 11] == want[: len(want) - 11]
+    # the GPU decoder returns the input
+    d_back = torch.empty(d.size + 64, dtype=torch.uint8, device="cuda")
+    rc, dn = ctx.decompress_device(d_out.data_ptr(), n1, d_back.data_ptr(), d.size)
+    assert rc == 0 and dn == d.size
+    assert torch.equal(d_back[:dn], d_in)
 
 
 def _repeat_family(seed):
