@@ -23,7 +23,7 @@ SYMBOLS = [
     "bz2hip_stream_pending", "bz2hip_rle1_split", "bz2hip_bwt", "bz2hip_mtf_rle2",
     "bz2hip_huffman", "bz2hip_block_compress", "bz2hip_profile_reset", "bz2hip_profile_get", "bz2hip_last_stats3",
     "bz2hip_last_stats", "bz2hip_last_stats2", "bz2hip_decompress", "bz2hip_decompress_device",
-    "bz2hip_shard_scan", "bz2hip_shard_chain",
+    "bz2hip_compress_device_noalloc", "bz2hip_shard_scan", "bz2hip_shard_chain",
     "bz2hip_shard_compress", "bz2hip_stitch_device",
 ]
 
@@ -112,6 +112,8 @@ def load():
     L.bz2hip_decompress.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
     L.bz2hip_decompress_device.restype = C.c_int
     L.bz2hip_decompress_device.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
+    L.bz2hip_compress_device_noalloc.restype = C.c_int
+    L.bz2hip_compress_device_noalloc.argtypes = [vp, vp, sz, C.c_int, vp, sz, C.POINTER(sz)]
     L.bz2hip_shard_scan.restype = C.c_int
     L.bz2hip_shard_scan.argtypes = [vp, vp, sz, C.c_int]
     L.bz2hip_shard_chain.restype = C.c_int
@@ -221,6 +223,13 @@ class Context:
                                                        C.c_void_p(d_out_ptr), cap, C.byref(nbits),
                                                        _p(crcs), mx, C.byref(nb)))
         return nbits.value, crcs[: nb.value].copy()
+
+    def compress_device_noalloc(self, d_in_ptr, n, level, d_out_ptr, cap):
+        """bz2hip_compress_device without any device allocation (static scratch; n <= 1 MiB)"""
+        got = C.c_size_t(0)
+        self._chk(self.L.bz2hip_compress_device_noalloc(self.h, C.c_void_p(d_in_ptr), n, level,
+                                                        C.c_void_p(d_out_ptr), cap, C.byref(got)))
+        return got.value
 
     # ---- one stream sharded over GPUs / processes (device pointers)
     def shard_scan(self, d_in_ptr, avail, level):

@@ -237,6 +237,13 @@ extern "C" size_t bz2hip_compress_bound(size_t n) {
 
 static std::string g_create_err = "no error";
 
+// Static scratch of the allocation-free entry point (bz2hip_compress_device_noalloc): every GPU
+// the library runs on holds its own copy of this array, at its own address, until the process
+// ends.  In host code the name is only a stand-in for hipGetSymbolAddress -- the kernels get the
+// per-device address kept in bz2hip_ctx::scratch, never the name.
+#define NOALLOC_SCRATCH_BYTES ((size_t)BZ2HIP_NOALLOC_SCRATCH_MIB << 20)
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+
 static int env_int(const char *name, int dflt) {
     const char *e = getenv(name);
     return e ? atoi(e) : dflt;
@@ -280,6 +287,10 @@ extern "C" int bz2hip_create(bz2hip_ctx **out, const bz2hip_opts *opts) {
         HIPCHK(hipEventCreateWithFlags(&c->crc_done, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        // this device's copy of the static scratch (device `dev` is current)
+        void *sp = nullptr;
+        HIPCHK(hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch)));
+        c->scratch = (u8 *)sp;
     } catch (const std::exception &e) {
         g_create_err = e.what();
         if (c->crc_done) (void)hipEventDestroy(c->crc_done);
@@ -487,6 +498,81 @@ extern "C" int bz2hip_compress_device(bz2hip_ctx *c, const void *d_in, size_t n,
         if (!d_out || !out_len || (n && !d_in)) return fail(c, BZ2HIP_E_PARAM, "null pointer");
         if (((uintptr_t)d_out & 3) != 0) return fail(c, BZ2HIP_E_PARAM, "d_out must be 4-byte aligned");
         if (cap < 64) return fail(c, BZ2HIP_E_CAP, "output buffer too small");
+        size_t zlen = std::min(cap, bz2hip_compress_bound(n)) & ~(size_t)3;
+        HIPCHK(hipMemsetAsync(d_out, 0, zlen, c->stream));
+        u64 bitpos = 32;
+        u32 scrc = 0;
+        compress_core(c, (const u8 *)d_in, n, level, (u8 *)d_out, zlen, &bitpos, &scrc, true, true);
+        *out_len = (size_t)((bitpos + 7) / 8);
+        return BZ2HIP_OK;
+    });
+}
+
+// ------------------------------------------------------------------ allocation-free variant
+// bz2hip_compress_device for callers that cannot allocate (code under HIP graph capture, tight
+// serving loops, harnesses that forbid hipMalloc): the whole workspace (K1 window scratch + one
+// batch) is carved from this GPU's copy of the static `scratch` array.  No hipMalloc / hipFree
+// on this path; events and streams were created by bz2hip_create.  Every call on a GPU shares
+// that GPU's array, so calls that overlap on one GPU (two contexts, two threads) race.
+extern "C" int bz2hip_compress_device_noalloc(bz2hip_ctx *c, const void *d_in, size_t n, int level,
+                                              void *d_out, size_t cap, size_t *out_len) {
+    return guarded(c, [&]() -> int {
+        if (level < 1 || level > 9) return fail(c, BZ2HIP_E_PARAM, "Invalid BZip2 block size");
+        if (!d_out || !out_len || (n && !d_in)) return fail(c, BZ2HIP_E_PARAM, "null pointer");
+        if (((uintptr_t)d_out & 3) != 0) return fail(c, BZ2HIP_E_PARAM, "d_out must be 4-byte aligned");
+        if (n > (size_t)BZ2HIP_NOALLOC_MAX_INPUT)
+            return fail(c, BZ2HIP_E_PARAM, "input larger than BZ2HIP_NOALLOC_MAX_INPUT (1 MiB): use bz2hip_compress_device");
+        if (cap < 64) return fail(c, BZ2HIP_E_CAP, "output buffer too small");
+        if (!c->scratch) return fail(c, BZ2HIP_E_STATE, "static scratch not resolved on this device");
+        if (c->fixed_ws) return fail(c, BZ2HIP_E_STATE, "allocation-free call already in progress");
+        // the context's own (allocated) workspace is set aside for the duration of the call
+        struct Saved {
+            bz2hip_ctx *c;
+            Batch batch;
+            u32 *w_rs, *w_P, *w_agg1, *w_agg2, *w_starts, *w_eagg, *w_cagg;
+            size_t w_cap;
+            u32 w_maxblocks, w_ETPB;
+            int w_eagg_nb;
+            bool profile;
+            explicit Saved(bz2hip_ctx *cc)
+                : c(cc), batch(std::move(cc->batch)), w_rs(cc->w_rs), w_P(cc->w_P), w_agg1(cc->w_agg1),
+                  w_agg2(cc->w_agg2), w_starts(cc->w_starts), w_eagg(cc->w_eagg), w_cagg(cc->w_cagg),
+                  w_cap(cc->w_cap), w_maxblocks(cc->w_maxblocks), w_ETPB(cc->w_ETPB),
+                  w_eagg_nb(cc->w_eagg_nb), profile(cc->profile) {
+                cc->batch = Batch();
+                cc->fixed_ws = true;
+                cc->profile = false; // the event pool may have to create events
+            }
+            ~Saved() {
+                c->batch = std::move(batch);
+                c->w_rs = w_rs; c->w_P = w_P; c->w_agg1 = w_agg1; c->w_agg2 = w_agg2;
+                c->w_starts = w_starts; c->w_eagg = w_eagg; c->w_cagg = w_cagg;
+                c->w_cap = w_cap; c->w_maxblocks = w_maxblocks; c->w_ETPB = w_ETPB;
+                c->w_eagg_nb = w_eagg_nb;
+                c->profile = profile;
+                c->fixed_ws = false;
+            }
+        } saved(c);
+        // carve: window scratch for n bytes, then as many block slots as fit
+        const size_t wlen = std::max<size_t>(n, 1);
+        const u32 mb = window_max_blocks(wlen, level);
+        const u32 ETPB = emit_tiles_per_block(level);
+        size_t off = layout_window(c, wlen, mb, c->scratch);
+        int nb = (int)std::min<size_t>(wlen / ((size_t)level * 100000 - 4) + 1, 64);
+        Batch N;
+        while (nb >= 1 && off + layout_batch(N, level, nb, nullptr) + layout_emit(c, nb, ETPB, nullptr) >
+                              NOALLOC_SCRATCH_BYTES)
+            nb--;
+        if (nb < 1) return fail(c, BZ2HIP_E_NOMEM, "static scratch too small for one block of this level");
+        off += layout_batch(N, level, nb, c->scratch + off);
+        off += layout_emit(c, nb, ETPB, c->scratch + off);
+        c->batch = std::move(N);
+        c->w_cap = wlen;
+        c->w_maxblocks = mb;
+        c->w_ETPB = ETPB;
+        c->w_eagg_nb = nb;
+        // the array keeps the last call's contents: the control words must start at zero
+        HIPCHK(hipMemsetAsync(c->batch.ctl, 0, 64 * sizeof(u32), c->stream));
         size_t zlen = std::min(cap, bz2hip_compress_bound(n)) & ~(size_t)3;
         HIPCHK(hipMemsetAsync(d_out, 0, zlen, c->stream));
         u64 bitpos = 32;

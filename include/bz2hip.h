@@ -94,6 +94,19 @@ int bz2hip_compress_blocks(bz2hip_ctx *ctx, const uint8_t *in, size_t n, int lev
                            size_t cap, uint64_t *nbits, uint32_t *crcs, uint32_t max_blocks,
                            uint32_t *n_blocks);
 
+/* Allocation-free variant of bz2hip_compress_device.  It has NO counterpart in the reference: it
+ * exists for callers that cannot allocate device memory -- code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  The whole workspace is carved from a static
+ * device array of BZ2HIP_NOALLOC_SCRATCH_MIB MiB that every GPU the library runs on holds until
+ * the process ends; the call makes no hipMalloc / hipFree.  n must not exceed
+ * BZ2HIP_NOALLOC_MAX_INPUT (BZ2HIP_E_PARAM otherwise); output is byte-identical to
+ * bz2hip_compress_device.  All calls on one GPU share that GPU's array: calls that overlap on one
+ * GPU (two contexts or two threads) race. */
+#define BZ2HIP_NOALLOC_SCRATCH_MIB 64
+#define BZ2HIP_NOALLOC_MAX_INPUT (1u << 20)
+int bz2hip_compress_device_noalloc(bz2hip_ctx *ctx, const void *d_in, size_t n, int level,
+                                   void *d_out, size_t cap, size_t *out_len);
+
 /* ---- one stream sharded over several GPUs / processes -----------------------------------
  * No counterpart in the reference (single-threaded, S/BZip2OutputStream.swift:29); the block
  * boundaries are those of BZip2BlockCompressor.write (S/BZip2BlockCompressor.swift:198-227), and
