@@ -24,13 +24,13 @@ SYMBOLS = [
     "bz2hip_huffman", "bz2hip_block_compress", "bz2hip_profile_reset", "bz2hip_profile_get", "bz2hip_last_stats3",
     "bz2hip_last_stats", "bz2hip_last_stats2", "bz2hip_decompress", "bz2hip_decompress_device",
     "bz2hip_compress_device_noalloc", "bz2hip_shard_scan", "bz2hip_shard_chain",
-    "bz2hip_shard_compress", "bz2hip_stitch_device",
+    "bz2hip_shard_compress", "bz2hip_stitch_device", "bz2hip_host_alloc", "bz2hip_host_free",
 ]
 
 
 class Opts(C.Structure):
     _fields_ = [("device", C.c_int), ("max_batch_blocks", C.c_int), ("tie_rule", C.c_int),
-                ("profile", C.c_int)]
+                ("profile", C.c_int), ("n_devices", C.c_int), ("devices", C.c_int * 8)]
 
 
 class BZ2HipError(RuntimeError):
@@ -120,6 +120,10 @@ def load():
     L.bz2hip_shard_chain.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int, u32p, C.POINTER(C.c_uint64)]
     L.bz2hip_shard_compress.restype = C.c_int
     L.bz2hip_shard_compress.argtypes = [vp, vp, sz, C.POINTER(C.c_uint64), vp, C.c_uint32, u32p]
+    L.bz2hip_host_alloc.restype = C.c_int
+    L.bz2hip_host_alloc.argtypes = [C.POINTER(vp), sz]
+    L.bz2hip_host_free.restype = None
+    L.bz2hip_host_free.argtypes = [vp]
     L.bz2hip_stitch_device.restype = C.c_int
     L.bz2hip_stitch_device.argtypes = [vp, C.c_int, C.c_uint32, vp, vp, vp, vp, vp, sz, C.POINTER(sz)]
     _lib = L
@@ -128,6 +132,30 @@ def load():
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+class PinnedBuffer:
+    """Page-locked host buffer (bz2hip_host_alloc) viewed as a numpy uint8 array (.a)."""
+
+    def __init__(self, nbytes):
+        self.L = load()
+        self.p = C.c_void_p()
+        rc = self.L.bz2hip_host_alloc(C.byref(self.p), nbytes)
+        if rc != OK:
+            raise BZ2HipError(rc, "bz2hip_host_alloc failed")
+        self.a = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(self.p.value))
+
+    def free(self):
+        if self.p:
+            self.a = None
+            self.L.bz2hip_host_free(self.p)
+            self.p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 def stitch(level, segments):
@@ -155,10 +183,15 @@ def stitch(level, segments):
 class Context:
     """One GPU compression context (bz2hip_ctx)."""
 
-    def __init__(self, device=-1, max_batch_blocks=0, tie_rule=0, profile=False):
+    def __init__(self, device=-1, max_batch_blocks=0, tie_rule=0, profile=False, devices=None):
+        """devices: list of HIP ordinals -> the host-buffer entry points shard every stream over them"""
         self.L = load()
         self.h = C.c_void_p()
         o = Opts(device, max_batch_blocks, tie_rule, int(profile))
+        if devices:
+            o.n_devices = len(devices)
+            for i, d in enumerate(devices):
+                o.devices[i] = d
         rc = self.L.bz2hip_create(C.byref(self.h), C.byref(o))
         if rc != OK:
             raise BZ2HipError(rc, "bz2hip_create failed: " +
@@ -188,6 +221,12 @@ class Context:
         n = C.c_size_t(0)
         self._chk(self.L.bz2hip_compress(self.h, _p(a), a.size, level, _p(out), cap, C.byref(n)))
         return out[: n.value].tobytes()
+
+    def compress_into(self, a, level, out):
+        """host arrays in / out (numpy uint8, e.g. PinnedBuffer.a) -> compressed length; no copies"""
+        n = C.c_size_t(0)
+        self._chk(self.L.bz2hip_compress(self.h, _p(a), a.size, level, _p(out), out.size, C.byref(n)))
+        return n.value
 
     # ---- decoder: (rc, bytes the reference would have handed out before failing); rc 0 = whole stream
     def decompress(self, stream, cap):

@@ -3,12 +3,16 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
+#include <thread>
 
 // Larger batches are faster (768 MiB: 6.9 GB/s at 256 blocks per batch, 7.5 GB/s at 384+); a
 // level-9 block costs ~37 MB of workspace, so 1024 blocks = 38 GB of the 288 GB.
 #define DEFAULT_BATCH_BLOCKS 1024
 #define WMAX (1u << 30) // window of input scanned at once (u32 prefix sums stay < 2^32)
+#define STREAM_CHUNK ((size_t)64 << 20) // streaming: input buffered per GPU before a flush
 
 // ------------------------------------------------------------------ workspace
 // A batch workspace is ONE device region carved into its arrays (256-byte aligned each), so that
@@ -261,12 +265,17 @@ extern "C" int bz2hip_create(bz2hip_ctx **out, const bz2hip_opts *opts) {
     bz2hip_ctx *c = new (std::nothrow) bz2hip_ctx();
     if (!c) return BZ2HIP_E_NOMEM;
     if (opts) c->opts = *opts;
-    else { c->opts.device = -1; c->opts.max_batch_blocks = 0; c->opts.tie_rule = 0; c->opts.profile = 0; }
-    int dev = c->opts.device;
+    else { c->opts = bz2hip_opts{}; c->opts.device = -1; }
+    if (c->opts.n_devices < 0 || c->opts.n_devices > BZ2HIP_MAX_DEVICES) {
+        g_create_err = "n_devices outside 0..8";
+        delete c;
+        return BZ2HIP_E_PARAM;
+    }
+    int dev = c->opts.n_devices >= 1 ? c->opts.devices[0] : c->opts.device;
     if (dev < 0) {
         if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     }
-    if (dev >= ndev) { delete c; return BZ2HIP_E_PARAM; }
+    if (dev >= ndev) { g_create_err = "no such device"; delete c; return BZ2HIP_E_PARAM; }
     c->device = dev;
     c->profile = c->opts.profile != 0;
     c->profile_level = c->opts.profile;
@@ -282,6 +291,7 @@ extern "C" int bz2hip_create(bz2hip_ctx **out, const bz2hip_opts *opts) {
     c->plain_mask = (u32)env_int("BZ2HIP_PLAIN", 2);
     c->r0bits = (u32)env_int("BZ2HIP_R0BITS", 40);
     c->r0_sweeps = (u32)std::min(16, std::max(1, env_int("BZ2HIP_RSWEEPS", 2)));
+    c->stream_chunk = (size_t)std::max(1, env_int("BZ2HIP_STREAM_CHUNK_MIB", (int)(STREAM_CHUNK >> 20))) << 20;
     try {
         k1_init_tables(c);
         HIPCHK(hipEventCreateWithFlags(&c->crc_done, hipEventDisableTiming));
@@ -301,13 +311,30 @@ extern "C" int bz2hip_create(bz2hip_ctx **out, const bz2hip_opts *opts) {
         delete c;
         return BZ2HIP_E_HIP;
     }
+    // one more single-device context per further entry of the device list
+    for (int k = 1; k < c->opts.n_devices; k++) {
+        bz2hip_opts po = c->opts;
+        po.n_devices = 0;
+        po.device = c->opts.devices[k] < 0 ? dev : c->opts.devices[k];
+        bz2hip_ctx *peer = nullptr;
+        int rc = bz2hip_create(&peer, &po);
+        if (rc != BZ2HIP_OK) {
+            bz2hip_destroy(c);
+            return rc;
+        }
+        c->peers.push_back(peer);
+    }
+    (void)hipSetDevice(dev);
     *out = c;
     return BZ2HIP_OK;
 }
 
 extern "C" void bz2hip_destroy(bz2hip_ctx *c) {
     if (!c) return;
+    for (bz2hip_ctx *p : c->peers) bz2hip_destroy(p);
+    c->peers.clear();
     (void)hipSetDevice(c->device);
+    if (c->d_shift) (void)hipFree(c->d_shift);
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamSynchronize(c->stream_other);
     dfree_all(c);
@@ -712,11 +739,272 @@ extern "C" int bz2hip_compress_blocks_device(bz2hip_ctx *c, const void *d_in, si
     });
 }
 
+extern "C" int bz2hip_host_alloc(void **p, size_t bytes) {
+    if (!p) return BZ2HIP_E_PARAM;
+    *p = nullptr;
+    hipError_t e = hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return e == hipErrorOutOfMemory ? BZ2HIP_E_NOMEM : BZ2HIP_E_HIP;
+    }
+    return BZ2HIP_OK;
+}
+
+extern "C" void bz2hip_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
+// ------------------------------------------------------------------ several GPUs behind one context
+static void append_bits(u8 *out, u64 *pos, const u8 *src, u64 nbits);
+static void append_value(u8 *out, u64 *pos, int cnt, u32 v);
+void run_place(bz2hip_ctx *c, const u8 *d_src, u64 nbits, u8 *d_out, u64 dst_bit); // k4_huffman.hip
+// One stream sharded over the context's device list (bz2hip_opts.n_devices): a worker thread per
+// GPU uploads its slice of the caller's buffer, scans it, takes its turn in the block chain (the
+// only serial step: one offset travels from worker to worker), compresses its blocks, shifts the
+// segment to its final bit offset on the device and downloads it straight into the caller's
+// output.  The calling thread orders everything: bit offsets, the CRC fold, the words two
+// segments share, header and trailer.
+struct ShardJob {
+    bz2hip_ctx *x = nullptr;
+    size_t lo = 0, hi = 0;        // nominal byte range of the round
+    size_t next = 0;              // where the following shard continues (absolute)
+    u64 nbits = 0, off = 0;       // segment length, final bit offset
+    std::vector<u32> crcs;
+    u8 edge[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}; // first / last word of the shifted segment
+    u64 edge_word[2] = {0, 0};
+    int n_edges = 0;
+    int rc = BZ2HIP_OK;
+};
+
+struct ChainHop {
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<long long> first; // -1: not known yet, -2: the shard before failed
+    void put(size_t r, long long v) {
+        {
+            std::lock_guard<std::mutex> g(m);
+            if (r < first.size() && first[r] == -1) first[r] = v;
+        }
+        cv.notify_all();
+    }
+    long long get(size_t r) {
+        std::unique_lock<std::mutex> g(m);
+        cv.wait(g, [&] { return first[r] != -1; });
+        return first[r];
+    }
+};
+
+// phase 1 of one worker: upload, scan, chain, compress (segment stays in x->h_out)
+static void shard_phase1(ShardJob &J, size_t r, size_t nw, const u8 *in, size_t n, int level, bool final_stream,
+                         ChainHop &hop) {
+    bz2hip_ctx *x = J.x;
+    J.rc = guarded(x, [&]() -> int {
+        const size_t bs = (size_t)level * 100000;
+        const size_t maxlook = bs * 52 + 65536;
+        size_t look = bs + 65536;
+        size_t uploaded = 0;
+        long long first = -1;
+        u32 nblocks = 0;
+        for (;;) {
+            const size_t end = std::min(n, J.hi + look);
+            const size_t avail = end - J.lo;
+            if (avail > WMAX) return fail(x, BZ2HIP_E_PARAM, "internal: shard larger than one window");
+            const u8 *old = x->h_in;
+            ensure_staging(x, avail, bz2hip_compress_bound(avail));
+            if (x->h_in != old) uploaded = 0;
+            if (avail > uploaded)
+                HIPCHK(hipMemcpyAsync(x->h_in + uploaded, in + J.lo + uploaded, avail - uploaded,
+                                      hipMemcpyHostToDevice, x->stream));
+            uploaded = avail;
+            int rc = bz2hip_shard_scan(x, x->h_in, avail, level);
+            if (rc != BZ2HIP_OK) return rc;
+            if (first < 0) first = hop.get(r);
+            if (first == -2) return fail(x, BZ2HIP_E_STATE, "the shard before this one failed");
+            // no block starts in this range: the previous shard's last block swallowed it, or (data
+            // not final) that block ran into the end of the data and the chain stops before it
+            if ((size_t)first >= J.hi || (size_t)first < J.lo) {
+                nblocks = 0;
+                J.next = (size_t)first;
+                break;
+            }
+            uint64_t nxt = 0;
+            rc = bz2hip_shard_chain(x, (u64)first - J.lo, J.hi - J.lo, (final_stream && end == n) ? 1 : 0,
+                                    &nblocks, &nxt);
+            if (rc != BZ2HIP_OK) return rc;
+            J.next = J.lo + (size_t)nxt;
+            if (J.next >= J.hi || end == n) break;
+            if (look >= maxlook) return fail(x, BZ2HIP_E_HIP, "block chain did not close within the maximum lookahead");
+            look = std::min(look * 4, maxlook); // the last block ran into the end of the slice
+        }
+        hop.put(r + 1, (long long)J.next);
+        J.nbits = 0;
+        J.crcs.clear();
+        if (nblocks) {
+            J.crcs.resize(nblocks);
+            u32 got = 0;
+            int rc = bz2hip_shard_compress(x, x->h_out, x->h_out_cap, &J.nbits, J.crcs.data(), nblocks, &got);
+            if (rc != BZ2HIP_OK) return rc;
+            J.crcs.resize(got);
+        }
+        return BZ2HIP_OK;
+    });
+    if (J.rc != BZ2HIP_OK) hop.put(r + 1, -2);
+    (void)nw;
+}
+
+// phase 2 of one worker: shift the segment to bit (off & 31) on the device, download its inner
+// words straight to their place in `out`, hand the two edge words to the calling thread
+static void shard_phase2(ShardJob &J, u8 *out) {
+    bz2hip_ctx *x = J.x;
+    J.n_edges = 0;
+    if (!J.nbits) return;
+    J.rc = guarded(x, [&]() -> int {
+        const u64 sh = J.off & 31;
+        const size_t W = (size_t)((sh + J.nbits + 31) / 32);
+        if (x->d_shift_cap < W * 4) {
+            x->d_shift_cap = 0;
+            if (x->d_shift) (void)hipFree(x->d_shift);
+            x->d_shift = nullptr;
+            HIPCHK(hipMalloc((void **)&x->d_shift, W * 4 + (W * 4) / 4 + 4096));
+            x->d_shift_cap = W * 4 + (W * 4) / 4 + 4096;
+        }
+        HIPCHK(hipMemsetAsync(x->d_shift, 0, W * 4, x->stream));
+        run_place(x, x->h_out, J.nbits, x->d_shift, sh);
+        const u64 w0 = J.off >> 5;
+        if (W > 2)
+            HIPCHK(hipMemcpyAsync(out + (w0 + 1) * 4, x->d_shift + 4, (W - 2) * 4, hipMemcpyDeviceToHost, x->stream));
+        HIPCHK(hipMemcpyAsync(J.edge[0], x->d_shift, 4, hipMemcpyDeviceToHost, x->stream));
+        J.edge_word[0] = w0;
+        J.n_edges = 1;
+        if (W > 1) {
+            HIPCHK(hipMemcpyAsync(J.edge[1], x->d_shift + (W - 1) * 4, 4, hipMemcpyDeviceToHost, x->stream));
+            J.edge_word[1] = w0 + W - 1;
+            J.n_edges = 2;
+        }
+        HIPCHK(hipStreamSynchronize(x->stream));
+        return BZ2HIP_OK;
+    });
+}
+
+// Compresses in[0..n) on all devices of the context into `out` starting at bit *bitpos (bits before it
+// inside its byte are kept).  Complete blocks only unless `final`; trailer only when `final`.
+// Returns the bytes consumed.
+static size_t multi_compress(bz2hip_ctx *c, const u8 *in, size_t n, int level, bool final, u8 *out,
+                             size_t cap, u64 *bitpos, u32 *stream_crc) {
+    std::vector<bz2hip_ctx *> devs;
+    devs.push_back(c);
+    for (bz2hip_ctx *p : c->peers) devs.push_back(p);
+    const size_t bs = (size_t)level * 100000;
+    struct { u64 blocks = 0, rounds = 0, rle = 0, periodic = 0, nr = 0, sorted = 0, s = 0, traps = 0; double bwt = 0; } tot;
+    size_t pos = 0;
+    // a round gives every worker at most ROUND_MAX bytes (+ lookahead <= one 1 GiB window)
+    const size_t ROUND_MAX = (size_t)768 << 20;
+    while (pos < n) {
+        const size_t left = n - pos;
+        size_t nw = std::min(devs.size(), std::max<size_t>(1, left / (2 * bs)));
+        const size_t span = std::min(left, nw * ROUND_MAX);
+        const bool last_round = (span == left);
+        std::vector<ShardJob> jobs(nw);
+        ChainHop hop;
+        hop.first.assign(nw + 1, -1);
+        hop.first[0] = (long long)pos;
+        for (size_t r = 0; r < nw; r++) {
+            jobs[r].x = devs[r];
+            jobs[r].lo = pos + (r == 0 ? 0 : (span * r / nw) / 4096 * 4096);
+            jobs[r].hi = (r + 1 == nw) ? pos + span : pos + (span * (r + 1) / nw) / 4096 * 4096;
+        }
+        const size_t vis = last_round ? n : std::min(n, pos + span + bs * 52 + 65536); // bytes a worker may look at
+        {
+            std::vector<std::thread> th;
+            for (size_t r = 1; r < nw; r++)
+                th.emplace_back(shard_phase1, std::ref(jobs[r]), r, nw, in, vis, level, final && last_round,
+                                std::ref(hop));
+            shard_phase1(jobs[0], 0, nw, in, vis, level, final && last_round, hop);
+            for (auto &t : th) t.join();
+        }
+        for (size_t r = 0; r < nw; r++)
+            if (jobs[r].rc != BZ2HIP_OK) {
+                if (jobs[r].x != c) c->err = jobs[r].x->err;
+                throw HipError(jobs[r].rc, c->err);
+            }
+        // ordered part 1: bit offsets, capacity, CRC fold
+        u64 p = *bitpos;
+        for (size_t r = 0; r < nw; r++) {
+            jobs[r].off = p;
+            p += jobs[r].nbits;
+        }
+        if ((p + 80 + 7) / 8 + 4 > cap) throw HipError(BZ2HIP_E_CAP, "output buffer too small");
+        {
+            std::vector<std::thread> th;
+            for (size_t r = 1; r < nw; r++) th.emplace_back(shard_phase2, std::ref(jobs[r]), out);
+            shard_phase2(jobs[0], out);
+            for (auto &t : th) t.join();
+        }
+        for (size_t r = 0; r < nw; r++)
+            if (jobs[r].rc != BZ2HIP_OK) {
+                if (jobs[r].x != c) c->err = jobs[r].x->err;
+                throw HipError(jobs[r].rc, c->err);
+            }
+        // ordered part 2: the words that two segments (or a segment and what was there) share
+        const u8 keep = (*bitpos & 7) ? (u8)(out[*bitpos >> 3] & (0xff00u >> (*bitpos & 7))) : 0;
+        for (size_t r = 0; r < nw; r++)
+            for (int e = 0; e < jobs[r].n_edges; e++)
+                for (int k = 0; k < 4; k++) {
+                    const u64 idx = jobs[r].edge_word[e] * 4 + k;
+                    if (idx >= (*bitpos >> 3) && idx < cap) out[idx] = 0;
+                }
+        if (*bitpos & 7) out[*bitpos >> 3] = keep;
+        for (size_t r = 0; r < nw; r++)
+            for (int e = 0; e < jobs[r].n_edges; e++)
+                for (int k = 0; k < 4; k++) {
+                    const u64 idx = jobs[r].edge_word[e] * 4 + k;
+                    if (idx < cap) out[idx] |= jobs[r].edge[e][k];
+                }
+        double round_bwt = 0;
+        for (size_t r = 0; r < nw; r++) {
+            for (u32 v : jobs[r].crcs) *stream_crc = ((*stream_crc << 1) | (*stream_crc >> 31)) ^ v;
+            bz2hip_ctx *x = jobs[r].x;
+            tot.blocks += x->st_blocks; tot.rounds += x->st_rounds; tot.rle += x->st_rle_bytes;
+            tot.periodic += x->st_periodic; tot.nr += x->st_nr; tot.sorted += x->st_sorted_elems;
+            tot.s += x->st_s_elems; tot.traps += x->st_tie_traps;
+            round_bwt = std::max(round_bwt, x->st_bwt_seconds);
+        }
+        tot.bwt += round_bwt;
+        *bitpos = p;
+        const size_t consumed = jobs[nw - 1].next - pos;
+        pos = jobs[nw - 1].next;
+        if (consumed == 0) break; // nothing but an incomplete block left
+        if (last_round) break;
+    }
+    c->st_blocks = tot.blocks; c->st_rounds = tot.rounds; c->st_rle_bytes = tot.rle; c->st_periodic = tot.periodic;
+    c->st_nr = tot.nr; c->st_sorted_elems = tot.sorted; c->st_s_elems = tot.s; c->st_tie_traps = tot.traps;
+    c->st_bwt_seconds = tot.bwt;
+    if (final) {
+        if ((*bitpos + 80 + 7) / 8 > cap) throw HipError(BZ2HIP_E_CAP, "output buffer too small");
+        if ((*bitpos & 7) == 0) out[*bitpos >> 3] = 0;
+        append_value(out, bitpos, 24, 0x177245);
+        append_value(out, bitpos, 24, 0x385090);
+        append_value(out, bitpos, 16, *stream_crc >> 16);
+        append_value(out, bitpos, 16, *stream_crc & 0xffff);
+    }
+    return pos;
+}
+
 extern "C" int bz2hip_compress(bz2hip_ctx *c, const uint8_t *in, size_t n, int level, uint8_t *out,
                                size_t cap, size_t *out_len) {
     return guarded(c, [&]() -> int {
         if (level < 1 || level > 9) return fail(c, BZ2HIP_E_PARAM, "Invalid BZip2 block size");
         if (!out || !out_len || (n && !in)) return fail(c, BZ2HIP_E_PARAM, "null pointer");
+        if (!c->peers.empty() && n >= (size_t)level * 400000) {
+            // several GPUs: one stream sharded over the device list
+            if (cap < 64) return fail(c, BZ2HIP_E_CAP, "output buffer too small");
+            out[0] = 0x42; out[1] = 0x5a; out[2] = 0x68; out[3] = (u8)('0' + level);
+            u64 bitpos = 32;
+            u32 scrc = 0;
+            multi_compress(c, in, n, level, true, out, cap, &bitpos, &scrc);
+            *out_len = (size_t)((bitpos + 7) / 8);
+            return BZ2HIP_OK;
+        }
         size_t bound = bz2hip_compress_bound(n);
         ensure_staging(c, n, bound);
         if (n) HIPCHK(hipMemcpyAsync(c->h_in, in, n, hipMemcpyHostToDevice, c->stream));
@@ -868,8 +1156,6 @@ extern "C" int bz2hip_stitch_device(bz2hip_ctx *c, int level, uint32_t nseg,
 }
 
 // ------------------------------------------------------------------ streaming
-#define STREAM_CHUNK ((size_t)64 << 20)
-
 extern "C" int bz2hip_stream_begin(bz2hip_ctx *c, int level) {
     if (!c) return BZ2HIP_E_PARAM;
     if (level < 1 || level > 9) return fail(c, BZ2HIP_E_PARAM, "Invalid BZip2 block size");
@@ -877,6 +1163,7 @@ extern "C" int bz2hip_stream_begin(bz2hip_ctx *c, int level) {
     c->s_open = true;
     c->s_finished = false;
     c->s_in.clear();
+    c->s_in_pos = 0;
     c->s_out.clear();
     c->s_out_pos = 0;
     c->s_stream_crc = 0;
@@ -891,23 +1178,33 @@ extern "C" int bz2hip_stream_begin(bz2hip_ctx *c, int level) {
 // compress what is buffered; only complete blocks unless final
 static int stream_flush(bz2hip_ctx *c, bool final) {
     return guarded(c, [&]() -> int {
-        const size_t n = c->s_in.size();
+        const u8 *src = c->s_in.data() + c->s_in_pos;
+        const size_t n = c->s_in.size() - c->s_in_pos;
         size_t bound = bz2hip_compress_bound(n) + 16;
-        ensure_staging(c, n, bound);
-        if (n) HIPCHK(hipMemcpyAsync(c->h_in, c->s_in.data(), n, hipMemcpyHostToDevice, c->stream));
-        size_t zlen = bound & ~(size_t)3;
-        HIPCHK(hipMemsetAsync(c->h_out, 0, zlen, c->stream));
-        const bool header = false; // already emitted by bz2hip_stream_begin
-        u64 bitpos = header ? 32 : (u64)c->s_bitcnt;
+        u64 bitpos = (u64)c->s_bitcnt; // the stream header went out with bz2hip_stream_begin
         u32 scrc = c->s_stream_crc;
-        size_t used = compress_core(c, c->h_in, n, c->s_level, c->h_out, zlen, &bitpos, &scrc, header, final);
+        std::vector<u8> tmp;
+        size_t used;
+        if (!c->peers.empty() && n >= (size_t)c->s_level * 400000) {
+            tmp.resize(bound);
+            tmp[0] = (u8)c->s_bitbuf;
+            used = multi_compress(c, src, n, c->s_level, final, tmp.data(), tmp.size(), &bitpos, &scrc);
+        } else {
+            ensure_staging(c, n, bound);
+            if (n) HIPCHK(hipMemcpyAsync(c->h_in, src, n, hipMemcpyHostToDevice, c->stream));
+            size_t zlen = bound & ~(size_t)3;
+            HIPCHK(hipMemsetAsync(c->h_out, 0, zlen, c->stream));
+            used = compress_core(c, c->h_in, n, c->s_level, c->h_out, zlen, &bitpos, &scrc, false, final);
+            if (final || used > 0) {
+                tmp.resize((size_t)((bitpos + 7) / 8));
+                if (!tmp.empty()) HIPCHK(hipMemcpy(tmp.data(), c->h_out, tmp.size(), hipMemcpyDeviceToHost));
+                if (c->s_bitcnt > 0) tmp[0] |= (u8)c->s_bitbuf;
+            }
+        }
         c->s_stream_crc = scrc;
         if (final || used > 0) {
-            size_t nbytes = (size_t)((bitpos + 7) / 8);
-            std::vector<u8> tmp(nbytes);
-            if (nbytes) HIPCHK(hipMemcpy(tmp.data(), c->h_out, nbytes, hipMemcpyDeviceToHost));
-            if (!header && c->s_bitcnt > 0) tmp[0] |= (u8)c->s_bitbuf;
-            size_t full = final ? nbytes : (size_t)(bitpos / 8);
+            const size_t nbytes = (size_t)((bitpos + 7) / 8);
+            const size_t full = final ? nbytes : (size_t)(bitpos / 8);
             c->s_out.insert(c->s_out.end(), tmp.begin(), tmp.begin() + full);
             if (!final) {
                 c->s_bitcnt = (int)(bitpos & 7);
@@ -917,7 +1214,15 @@ static int stream_flush(bz2hip_ctx *c, bool final) {
                 c->s_bitbuf = 0;
             }
         }
-        c->s_in.erase(c->s_in.begin(), c->s_in.begin() + used);
+        // consumed input is dropped lazily: no quadratic erase per flush
+        c->s_in_pos += used;
+        if (c->s_in_pos == c->s_in.size()) {
+            c->s_in.clear();
+            c->s_in_pos = 0;
+        } else if (c->s_in_pos > (c->s_in.size() >> 1)) {
+            c->s_in.erase(c->s_in.begin(), c->s_in.begin() + c->s_in_pos);
+            c->s_in_pos = 0;
+        }
         return BZ2HIP_OK;
     });
 }
@@ -931,7 +1236,7 @@ extern "C" int bz2hip_stream_write(bz2hip_ctx *c, const uint8_t *p, size_t n) {
     } catch (const std::bad_alloc &) {
         return fail(c, BZ2HIP_E_NOMEM, "host allocation failed");
     }
-    if (c->s_in.size() >= STREAM_CHUNK) return stream_flush(c, false);
+    if (c->s_in.size() - c->s_in_pos >= c->stream_chunk * (c->peers.size() + 1)) return stream_flush(c, false);
     return BZ2HIP_OK;
 }
 

@@ -114,6 +114,7 @@ struct bz2hip_ctx {
     u32 plain_mask = 2;      // BZ2HIP_PLAIN
     u32 r0bits = 40;         // BZ2HIP_R0BITS
     u32 r0_sweeps = 2;       // BZ2HIP_RSWEEPS
+    size_t stream_chunk = (size_t)64 << 20; // BZ2HIP_STREAM_CHUNK_MIB: streaming flush threshold per GPU
     bool fixed_ws = false;   // allocation-free call in progress: workspace carved from the static scratch
     u8 *scratch = nullptr;   // this device's address of the static scratch array (api.hip)
     hipEvent_t crc_done = nullptr;
@@ -140,6 +141,11 @@ struct bz2hip_ctx {
     u64 st_s_elems = 0;      // elements sorted by the LDS (S) path, summed over rounds
     u64 st_sorted_elems = 0; // sum over radix passes of elements moved
     u64 st_nr = 0;           // sum over blocks of n_b * doubling rounds_b
+    // several GPUs behind one context: peers[k] drives opts.devices[k + 1] (this context is device 0
+    // of the list); every device shifts its segment to its bit offset in d_shift before the download
+    std::vector<bz2hip_ctx *> peers;
+    u8 *d_shift = nullptr;
+    size_t d_shift_cap = 0;
     // sharding state (bz2hip_shard_scan / _chain / _compress)
     const u8 *sh_in = nullptr;
     size_t sh_avail = 0;
@@ -150,7 +156,8 @@ struct bz2hip_ctx {
     // streaming state
     int s_level = 0;
     bool s_open = false, s_finished = false;
-    std::vector<u8> s_in;      // buffered, not yet compressed input
+    std::vector<u8> s_in;      // buffered, not yet compressed input (from s_in_pos on)
+    size_t s_in_pos = 0;
     std::vector<u8> s_out;     // compressed bytes not yet drained
     size_t s_out_pos = 0;
     u32 s_stream_crc = 0;

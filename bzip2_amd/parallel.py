@@ -61,8 +61,10 @@ def run_rank(engine, level, rank, world, n_total, recv_first=None, send_next=Non
         if first is None:
             first = 0 if rank == 0 else int(recv_first())
         final = end == n_total
-        if first >= hi:
-            nblocks, nxt = 0, first        # the previous rank's last block swallowed this range
+        if first >= hi or first < lo:
+            # no block starts here: the previous rank's last block swallowed this range (or, with a
+            # stream that is not final, ran into the end of the data)
+            nblocks, nxt = 0, first
             break
         nblocks, nxt_rel = engine.chain(first - lo, hi - lo, final)
         nxt = lo + nxt_rel

@@ -52,12 +52,22 @@ typedef struct bz2hip_ctx bz2hip_ctx;
 #define BZ2HIP_TIE_FIRST 1
 #define BZ2HIP_TIE_LAST 2
 
+#define BZ2HIP_MAX_DEVICES 8
+
 typedef struct bz2hip_opts {
-    int device;            /* HIP device ordinal; -1 = current device */
+    int device;            /* HIP device ordinal; -1 = current device (used when n_devices <= 1) */
     int max_batch_blocks;  /* blocks sorted per batch (0 = default 1024) */
     int tie_rule;          /* origin pointer of periodic blocks (block == w^k): BZ2HIP_TIE_* */
     int profile;           /* HIP-event timing per kernel class (bz2hip_profile_*): 1 = the
                               bandwidth-bound kernels only (cheap), 2 = every class */
+    int n_devices;         /* 0 or 1: one GPU (`device`).  2..8: the host-buffer entry points
+                              (bz2hip_compress, bz2hip_stream_*) shard every stream over
+                              devices[0..n_devices): one worker thread and one block queue per GPU,
+                              ordered concatenation on the calling thread (the reference has one
+                              writer per stream, S/BZip2OutputStream.swift:29).  An ordinal may
+                              appear more than once (two workers on one GPU).  Device-pointer and
+                              stage entry points run on devices[0]. */
+    int devices[BZ2HIP_MAX_DEVICES];
 } bz2hip_opts;
 
 /* Context life cycle (no counterpart in the reference; holds the GPU workspace). */
@@ -65,6 +75,13 @@ int bz2hip_create(bz2hip_ctx **ctx, const bz2hip_opts *opts);
 void bz2hip_destroy(bz2hip_ctx *ctx);
 const char *bz2hip_last_error(const bz2hip_ctx *ctx);
 const char *bz2hip_version(void);
+
+/* Page-locked host memory for the buffers handed to the host-pointer entry points: transfers from
+ * and to such buffers run at the full PCIe rate and asynchronously (pageable memory is staged by
+ * the runtime at roughly half the rate).  A binding that owns its buffers -- as the reference's
+ * BZip2BlockCompressor owns `block` (S/BZip2BlockCompressor.swift:317) -- allocates them here. */
+int bz2hip_host_alloc(void **p, size_t bytes);
+void bz2hip_host_free(void *p);
 
 /* Upper bound of the compressed size of n input bytes (stream header + trailer included). */
 size_t bz2hip_compress_bound(size_t n);

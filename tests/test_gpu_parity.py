@@ -421,3 +421,43 @@ def test_more_blocks_than_estimated(ctx, orc):
         assert nb > d.size // (level * 100000 - 4) + 1
         got = ctx.compress(d, level)
         assert got == want, level
+
+
+def test_multi_device_context(orc):
+    """bz2hip_opts.n_devices / devices[]: the host-buffer entry points shard one stream over the
+    device list -- here the one GPU of the box several times (a worker thread, a context, streams
+    and a workspace per entry) -- and the bytes equal the oracle's, whatever the list."""
+    import bzip2_amd
+    d3 = np.concatenate((corpus.mixed(6, 91, seg_bytes=700000), np.zeros(5_000_000, dtype=np.uint8),
+                         corpus.mixed(5, 92, seg_bytes=600000)))
+    want3, _ = orc.compress(d3, 3, threads=8)
+    d9 = corpus.mixed(20, corpus.STREAM1G_SEED)
+    want9, _ = orc.compress(d9, 9, threads=8)
+    for devices in ([0, 0], [0, 0, 0], [0] * 5):
+        os.environ["BZ2HIP_STREAM_CHUNK_MIB"] = "2"   # several intermediate flushes per stream
+        try:
+            c = bzip2_amd.Context(devices=devices, max_batch_blocks=16)
+        finally:
+            del os.environ["BZ2HIP_STREAM_CHUNK_MIB"]
+        try:
+            assert c.compress(d3, 3) == want3, devices
+            assert c.last_stats()["blocks"] >= 15
+            assert c.compress(d9, 9) == want9, devices
+            assert c.compress(d3[:1000], 3) == orc.compress(d3[:1000], 3)[0]   # below the sharding threshold
+            assert c.compress(b"", 3) == bytes.fromhex("425a683317724538509000000000")
+            # streaming through the same device list, ragged writes
+            rng = np.random.default_rng(len(devices))
+            c.stream_begin(3)
+            pos = 0
+            raw = d3.tobytes()
+            while pos < len(raw):
+                k = int(rng.integers(1, 3_000_000))
+                c.stream_write(raw[pos:pos + k])
+                pos += k
+            c.stream_finish()
+            out = b""
+            while c.stream_pending():
+                out += c.stream_read(1 << 20)
+            assert out == want3, devices
+        finally:
+            c.close()
