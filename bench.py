@@ -2,15 +2,26 @@
 """bench.py -- compress MB/s (uncompressed input) at -9 on N MI355X GPUs.
 
 One step = one pass of the whole hot path (block split + RLE1 + CRC, BWT, MTF/RLE2, Huffman,
-bit packing, framing) over the synthetic `mixed256` corpus (256 x 1 MiB segments, SURVEY §8(d)
-config 3), input and output resident in HBM.  With N > 1 every rank compresses its own 256 MiB
-shard of the `stream1g` generator (weak scaling, no collective on the data path).
+bit packing, framing) over synthetic data resident in HBM, ending with the complete .bz2 stream
+resident in HBM.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant
-kernel = the LSD radix scatter pass of the BWT) and `cpu_baseline` (the CPU oracle, timed on a
-bounded sample of the same workload on this host).
+N = 1: the `mixed256` corpus (256 x 1 MiB segments) through
+       bz2hip_compress_device.
+N > 1: ONE stream of N x 256 MiB of the `stream1g` generator (config 4; N = 4 is exactly the 1 GiB
+       stream) sharded over the ranks: every rank holds its byte range (+ lookahead) in HBM and
+       scans it, the block chain hops from rank to rank (one integer), every rank compresses its
+       blocks, rank 0 gathers the bit segments and concatenates them in order on its GPU.  Scan,
+       chain, compression, gather and stitch are all inside the timed region; rank 0 then checks
+       the stream against the one it compresses alone from the same data (SHA-256) and through
+       the GPU decoder.  Per-GPU work is fixed as N grows ("weak").
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel by
+GPU time) and, at N = 1, `cpu_baseline` (the CPU oracle timed on a bounded sample of the same
+workload on this host) and `host_to_host` (the same step through bz2hip_compress from and to host
+buffers, PCIe included: SURVEY §8(d)'s wall-clock definition; never `value`).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -20,6 +31,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+KERNEL = {"radix_scatter": "k2_radix_scatter", "radix_hist": "k2_radix_hist",
+          "bwt_keys": "k2_keys", "bwt_ssort": "k2_ssort", "mtf_replay": "k3_mtf_replay"}
+PMC_NAME = {"k2_ssort": "void k2_ssort<0>", "k2_radix_scatter": "void k2_radix_scatter<false>",
+            "k2_radix_hist": "void k2_radix_hist<false>"}
+
+
+def load_pmc():
+    for name in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return name, json.load(f)
+        except (OSError, ValueError):
+            continue
+    return None, {}
 
 
 def main():
@@ -31,6 +56,7 @@ def main():
     ap.add_argument("--level", type=int, default=9)
     ap.add_argument("--batch", type=int, default=0, help="blocks per batch (0 = library default)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-host", action="store_true", help="skip the host_to_host leg")
     ap.add_argument("--cpu-sample-mib", type=int, default=48)
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--profile-all", action="store_true",
@@ -44,42 +70,121 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE {world}: launch with torch.distributed.run "
+              f"--nproc-per-node {args.gpus}; running with {world} rank(s)", file=sys.stderr)
     # rehearsal on a one-GPU box: BZ2_BENCH_BACKEND=gloo BZ2_BENCH_ONE_GPU=1 puts every rank on cuda:0
     backend = os.environ.get("BZ2_BENCH_BACKEND", "nccl")
     if os.environ.get("BZ2_BENCH_ONE_GPU"):
         local_rank = 0
+    hop_group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            hop_group = dist.new_group(backend="gloo")  # the block chain: one int64 per hop, host side
         else:
             dist.init_process_group(backend=backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    from bzip2_amd import Context, corpus
+    from bzip2_amd import Context, PinnedBuffer, corpus, parallel
+
+    prof_level = 0 if args.no_profile else (2 if args.profile_all else 1)
+    ctx = Context(device=local_rank, max_batch_blocks=args.batch, profile=prof_level)
+    L = ctx.L
+    seg = args.segments
+    level = args.level
 
     if world == 1:
-        data = corpus.mixed(args.segments, corpus.MIXED256_SEED)
-        workload = f"mixed{args.segments} ({args.segments} x 1 MiB segments, 8 kinds cycling)"
+        data = corpus.mixed(seg, corpus.MIXED256_SEED)
+        workload = f"mixed{seg} ({seg} x 1 MiB segments, 8 kinds cycling), one stream on one GPU"
+        n_in = int(data.size)
+        n_total = n_in
+        d_in = torch.from_numpy(data).to(dev)
+        cap = L.bz2hip_compress_bound(n_in)
+        d_out = torch.empty(cap + 64, dtype=torch.uint8, device=dev)
+        out_len = 0
+
+        def step():
+            return ctx.compress_device(d_in.data_ptr(), n_in, level, d_out.data_ptr(), cap)
     else:
-        data = corpus.mixed(args.segments, corpus.STREAM1G_SEED + rank * args.segments)
-        workload = (f"stream1g shard: {args.segments} x 1 MiB segments per GPU, "
-                    f"{world * args.segments} MiB total")
-    n_in = int(data.size)
-    d_in = torch.from_numpy(data).to(dev)
-    ctx = Context(device=local_rank, max_batch_blocks=args.batch, profile=0 if args.no_profile else (2 if args.profile_all else 1))
-    L = ctx.L
-    cap = L.bz2hip_compress_bound(n_in)
-    d_out = torch.empty(cap + 64, dtype=torch.uint8, device=dev)
+        # one stream of world x seg MiB; rank r holds [lo, end) = its nominal range + lookahead
+        n_total = world * seg * corpus.MIB
+        lo, hi = parallel.nominal_ranges(n_total, world)[rank]
+        look_segs = 2  # a block that starts in this rank's last segment ends within the next two
+        s0, s1 = lo // corpus.MIB, min(world * seg, hi // corpus.MIB + look_segs)
+        parts = [corpus.segment(corpus._KINDS[i % 8], corpus.MIB, corpus.STREAM1G_SEED + i) for i in range(s0, s1)]
+        mine = np.concatenate(parts)
+        end = s1 * corpus.MIB
+        d_slice = torch.from_numpy(mine).to(dev)
+        n_in = hi - lo
+        workload = (f"stream1g generator, ONE stream of {world * seg} MiB sharded over {world} GPUs "
+                    f"({seg} MiB per GPU), ordered concatenation on rank 0's GPU")
+        eng = parallel.GpuShardEngine(ctx, local_rank)
+        eng.bind_device(d_slice, lo, end)
+        cap_seg = L.bz2hip_compress_bound(n_in + look_segs * corpus.MIB)
+        seg_words = (cap_seg + 3) // 4 * 4
+        # rank 0: receive buffers for every other rank's segment, and the stream
+        if rank == 0:
+            d_recv = [None] + [torch.empty(seg_words + 64, dtype=torch.uint8, device=dev) for _ in range(1, world)]
+            cap = L.bz2hip_compress_bound(n_total)
+            d_out = torch.empty(cap + 64, dtype=torch.uint8, device=dev)
+        cpu_comm = backend != "nccl"
+        hop_t = torch.zeros(1, dtype=torch.int64)
+        MAXCRC = n_in // (level * 50000) + 16
 
-    def step():
-        return ctx.compress_device(d_in.data_ptr(), n_in, args.level, d_out.data_ptr(), cap)
+        def recv_first():
+            dist.recv(hop_t, src=rank - 1, group=hop_group)
+            return int(hop_t.item())
 
-    out_len = 0
-    for _ in range(args.warmup):
-        out_len = step()
-    ctx.profile_reset()
+        def send_next(v):
+            dist.send(torch.tensor([v], dtype=torch.int64), dst=rank + 1, group=hop_group)
+
+        def step():
+            # scan + chain hop + compress (bzip2_amd/parallel.py: run_rank through the C ABI)
+            eng.compress = eng.compress_device
+            eng.empty = lambda: (eng.d_out if eng.d_out is not None else torch.zeros(8, dtype=torch.uint8, device=dev), 0,
+                                 np.zeros(0, dtype=np.uint32))
+            d_seg, nbits, crcs = parallel.run_rank(eng, level, rank, world, n_total, recv_first, send_next,
+                                                   lookahead=end - hi if rank + 1 < world else 0)
+            # gather: sizes + CRCs (host, tiny), then the bit segments (device to device)
+            meta = torch.zeros(2 + MAXCRC, dtype=torch.int64)
+            meta[0] = nbits
+            meta[1] = len(crcs)
+            meta[2:2 + len(crcs)] = torch.from_numpy(crcs.astype(np.int64))
+            metas = [torch.zeros_like(meta) for _ in range(world)] if rank == 0 else None
+            dist.gather(meta, metas, dst=0, group=hop_group)
+            nbytes = (nbits + 31) // 32 * 4
+            if rank == 0:
+                ops, segs = [], []
+                for r in range(world):
+                    nb_r, nc_r = int(metas[r][0]), int(metas[r][1])
+                    cr = metas[r][2:2 + nc_r].numpy().astype(np.uint32)
+                    if r == 0:
+                        segs.append((d_seg.data_ptr(), nb_r, cr))
+                        continue
+                    k = (nb_r + 31) // 32 * 4
+                    if k:
+                        if cpu_comm:
+                            buf = torch.empty(k, dtype=torch.uint8)
+                            dist.recv(buf, src=r)
+                            d_recv[r][:k].copy_(buf)
+                        else:
+                            ops.append(dist.P2POp(dist.irecv, d_recv[r][:k], r))
+                    segs.append((d_recv[r].data_ptr(), nb_r, cr))
+                if ops:
+                    for w in dist.batch_isend_irecv(ops):
+                        w.wait()
+                torch.cuda.synchronize()
+                return ctx.stitch_device(level, segs, d_out.data_ptr(), cap)
+            if nbytes:
+                if cpu_comm:
+                    dist.send(d_seg[:nbytes].cpu(), dst=0)
+                else:
+                    for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, d_seg[:nbytes], 0)]):
+                        w.wait()
+            return 0
 
     def barrier():
         torch.cuda.synchronize()
@@ -87,6 +192,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    for _ in range(args.warmup):
+        out_len = step()
+    ctx.profile_reset()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -98,22 +206,39 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # correctness guard on rank 0 (outside the timed region): the stream must round-trip
-    ok = True
-    if rank == 0:
-        import bz2
-        comp = d_out[:out_len].cpu().numpy().tobytes()
-        try:
-            ok = bz2.decompress(comp) == data.tobytes()
-        except (OSError, ValueError):
-            ok = False
-
     stats = ctx.last_stats()
     prof = ctx.profile_get() if not args.no_profile else {}
 
+    # correctness guard on rank 0 (outside the timed region)
+    check = {}
+    if rank == 0:
+        comp = d_out[:out_len].cpu().numpy().tobytes()
+        if world == 1:
+            import bz2
+            try:
+                check["roundtrip_ok"] = bz2.decompress(comp) == data.tobytes()
+            except (OSError, ValueError):
+                check["roundtrip_ok"] = False
+        else:
+            # the same data as one stream on this GPU alone: must be the same bytes
+            whole = corpus.mixed(world * seg, corpus.STREAM1G_SEED)
+            d_whole = torch.from_numpy(whole).to(dev)
+            c1 = Context(device=local_rank)
+            cap1 = L.bz2hip_compress_bound(n_total)
+            d_one = torch.empty(cap1 + 64, dtype=torch.uint8, device=dev)
+            n1 = c1.compress_device(d_whole.data_ptr(), n_total, level, d_one.data_ptr(), cap1)
+            one = d_one[:n1].cpu().numpy().tobytes()
+            check["sha256"] = hashlib.sha256(comp).hexdigest()
+            check["equals_single_gpu_stream"] = (hashlib.sha256(one).hexdigest() == check["sha256"])
+            d_back = torch.empty(n_total + 64, dtype=torch.uint8, device=dev)
+            drc, dn = c1.decompress_device(d_out.data_ptr(), out_len, d_back.data_ptr(), n_total)
+            check["roundtrip_ok"] = bool(drc == 0 and dn == n_total and torch.equal(d_back[:dn], d_whole))
+            c1.close()
+            del d_whole, d_one, d_back
+
     res = None
     if rank == 0:
-        total_bytes = n_in * world * args.steps
+        total_bytes = n_total * args.steps
         value = total_bytes / dt / 1e6
         res = {
             "metric": "compress MB/s (uncompressed input) at -9",
@@ -128,37 +253,33 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": workload, "level": args.level, "input_bytes_per_gpu": n_in,
-                       "blocks_per_gpu": stats["blocks"], "compressed_bytes_rank0": out_len,
-                       "roundtrip_ok": ok, "parallelism": f"blocks-sharded x{world}"},
+            "config": {"workload": workload, "level": level, "input_bytes_per_gpu": n_in,
+                       "stream_bytes": n_total, "blocks_rank0": stats["blocks"],
+                       "compressed_bytes": out_len, "parallelism": f"blocks-sharded x{world}", **check},
         }
         if prof:
             # dominant kernel class = the one with the most GPU time among those with a defined
             # algorithmic byte count
-            KERNEL = {"radix_scatter": "k2_radix_scatter", "radix_hist": "k2_radix_hist",
-                      "bwt_keys": "k2_keys", "bwt_ssort": "k2_ssort", "mtf_replay": "k3_mtf_replay"}
             dom = max(KERNEL, key=lambda k: prof[k]["ms"])
             sc = prof[dom]
             launches = max(sc["launches"], 1)
             avg_ms = sc["ms"] / launches
             alg = sc["alg_bytes"] / launches
             achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-            # HBM bytes per launch from the committed PMC passes of this same command
-            # (profiles/r1_pmc_traffic.json, made by tools/profile_round.sh)
-            traffic = None
+            # HBM bytes per launch from the committed PMC passes of this same command at N = 1
+            # (profiles/r*_pmc_traffic.json, made by tools/profile_round.sh)
+            pmc_file, pmc = load_pmc()
+            if not (world == 1 and seg == 256 and level == 9):
+                pmc_file, pmc = None, {}  # the PMC passes were made on the N = 1 headline workload
             try:
-                with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
-                    pmc = json.load(f)
-                pmc_name = {"k2_ssort": "void k2_ssort<0>",
-                            "k2_radix_scatter": "void k2_radix_scatter<false>",
-                            "k2_radix_hist": "void k2_radix_hist<false>"}
-                traffic = pmc[pmc_name.get(KERNEL[dom], KERNEL[dom])]["hbm_bytes_per_call"]
-            except (OSError, ValueError, KeyError):
+                traffic = pmc[PMC_NAME.get(KERNEL[dom], KERNEL[dom])]["hbm_bytes_per_call"]
+            except KeyError:
                 traffic = None
             res["roofline"] = {"bound": "hbm", "kernel": KERNEL[dom],
                                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                               "traffic": traffic, "avg_launch_ms": round(avg_ms, 4),
+                               "traffic": traffic, "traffic_source": pmc_file,
+                               "avg_launch_ms": round(avg_ms, 4),
                                "launches": launches, "alg_bytes_per_launch": round(alg)}
             res["kernel_rooflines"] = {
                 KERNEL[k]: {"ms_per_step": round(prof[k]["ms"] / args.steps, 3),
@@ -169,38 +290,64 @@ def main():
             t_bwt = stats["bwt_seconds"]
             n_rle = stats["rle_bytes"]
             # B_bwt = 15 n + 140 R n; our first sort reaches depth d0 = 5 symbols (byte
-            # alphabets), which plain doubling from depth 1 reaches in log2(5) = 2.32 rounds
+            # alphabets), which plain doubling from depth 1 reaches in log2(5) = 2.32 rounds.  This is
+            # the byte count of a FULL-WIDTH sorter, divided by the time of one that skips most of that
+            # work: an equivalent rate, not achieved bandwidth.  physical_frac = bytes the k2 kernels
+            # really moved (PMC, at N = 1) / that time / peak.
             b_bwt = 15.0 * n_rle + 140.0 * (stats["n_times_rounds"] + 2.32 * n_rle)
+            phys = sum(v["hbm_bytes_per_call"] * v["calls"] for k, v in pmc.items()
+                       if "k2_" in k and "hbm_bytes_per_call" in v) if pmc else None
             res["bwt_stage"] = {"seconds_per_step": round(t_bwt, 5),
-                                "alg_GBs": round(b_bwt / t_bwt / 1e9, 1) if t_bwt > 0 else None,
-                                "frac_of_hbm_peak": round(b_bwt / t_bwt / 1e9 / HBM_PEAK_GBS, 4) if t_bwt > 0 else None,
+                                "full_width_equivalent_GBs": round(b_bwt / t_bwt / 1e9, 1) if t_bwt > 0 else None,
+                                "frac_full_width_equivalent": round(b_bwt / t_bwt / 1e9 / HBM_PEAK_GBS, 4) if t_bwt > 0 else None,
+                                "physical_GBs": round(phys / t_bwt / 1e9, 1) if (phys and t_bwt > 0) else None,
+                                "physical_frac": round(phys / t_bwt / 1e9 / HBM_PEAK_GBS, 4) if (phys and t_bwt > 0) else None,
                                 "mean_doubling_rounds": round(stats["rounds_sum"] / max(stats["blocks"], 1), 2),
                                 "periodic_blocks": stats["periodic_blocks"]}
             res["stage_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in prof.items() if v["launches"]}
-        # the decoder on the stream just written: informational, one pass, untimed
-        # region of the headline metric
-        d_back = torch.empty(n_in + 64, dtype=torch.uint8, device=dev)
-        torch.cuda.synchronize()
-        td = time.perf_counter()
-        drc, dn = ctx.decompress_device(d_out.data_ptr(), out_len, d_back.data_ptr(), n_in)
-        torch.cuda.synchronize()
-        td = time.perf_counter() - td
-        res["decode"] = {"value": round(n_in / td / 1e6, 1), "unit": "MB/s", "ms": round(td * 1e3, 1),
-                         "ok": bool(drc == 0 and dn == n_in and torch.equal(d_back[:dn], d_in))}
-        del d_back
+        if world == 1:
+            # the decoder on the stream just written: informational, one pass
+            d_back = torch.empty(n_in + 64, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            td = time.perf_counter()
+            drc, dn = ctx.decompress_device(d_out.data_ptr(), out_len, d_back.data_ptr(), n_in)
+            torch.cuda.synchronize()
+            td = time.perf_counter() - td
+            res["decode"] = {"value": round(n_in / td / 1e6, 1), "unit": "MB/s", "ms": round(td * 1e3, 1),
+                             "ok": bool(drc == 0 and dn == n_in and torch.equal(d_back[:dn], d_in))}
+            del d_back
+        if world == 1 and not args.no_host:
+            # SURVEY §8(d)'s definition: first byte submitted to last output byte in host memory,
+            # through bz2hip_compress (PCIe both ways inside the clock).  Never `value`.
+            h2h = {}
+            out_host = np.empty(cap, dtype=np.uint8)
+            pin_in, pin_out = PinnedBuffer(n_in), PinnedBuffer(cap)
+            pin_in.a[:] = data
+            for name, src, dst in (("pageable", data, out_host), ("pinned", pin_in.a, pin_out.a)):
+                ctx.compress_into(src, level, dst)
+                th = time.perf_counter()
+                for _ in range(max(args.steps, 1)):
+                    got = ctx.compress_into(src, level, dst)
+                th = (time.perf_counter() - th) / max(args.steps, 1)
+                h2h[name] = {"value": round(n_in / th / 1e6, 1), "unit": "MB/s", "ms_per_step": round(th * 1e3, 2),
+                             "same_bytes": bool(got == out_len and dst[:got].tobytes() == comp)}
+            h2h["ratio_pinned_to_device_resident"] = round(h2h["pinned"]["value"] / value, 3)
+            res["host_to_host"] = h2h
+            pin_in.free()
+            pin_out.free()
         if not args.no_cpu and world == 1:  # the CPU baseline is timed at N = 1 only
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import orc  # CPU oracle: test infrastructure, used here only as the timed baseline
             sample = data[: min(n_in, args.cpu_sample_mib << 20)]
             tc = time.perf_counter()
-            o1, _ = orc.compress(sample, args.level, threads=1)
+            o1, _ = orc.compress(sample, level, threads=1)
             t1 = time.perf_counter() - tc
             cores = min(os.cpu_count() or 1, 16)
             tc = time.perf_counter()
-            o2, _ = orc.compress(sample, args.level, threads=cores)
+            o2, _ = orc.compress(sample, level, threads=cores)
             tm = time.perf_counter() - tc
             # the same sample through the GPU path must give the oracle's bytes (checker, not timed)
-            ln = ctx.compress_device(d_in.data_ptr(), int(sample.size), args.level, d_out.data_ptr(), cap)
+            ln = ctx.compress_device(d_in.data_ptr(), int(sample.size), level, d_out.data_ptr(), cap)
             same = d_out[:ln].cpu().numpy().tobytes() == bytes(o1) and bytes(o1) == bytes(o2)
             res["cpu_baseline"] = {"value": round(sample.size / t1 / 1e6, 2), "unit": "MB/s",
                                    "cores": 1, "kind": "port",

@@ -3,4 +3,4 @@
 Host-side mirror of the reference interface lives in bzip2_amd.streams; the compute path is
 libbz2hip.so (HIP, gfx950) behind the C ABI of include/bz2hip.h.
 """
-from ._lib import Context, BZ2HipError, load, SO_PATH, SYMBOLS  # noqa: F401
+from ._lib import Context, BZ2HipError, PinnedBuffer, load, SO_PATH, SYMBOLS  # noqa: F401
