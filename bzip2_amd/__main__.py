@@ -28,11 +28,13 @@ def main(argv=None):
 
     def decode(z):
         cap = max(len(z) * 6, 1 << 20)
+        # no stream expands by more than ~1.24 million (a block of 255-runs: 45.9 MB from ~37 bytes)
+        cap_max = len(z) * 1250000 + (1 << 20)
         while True:
             code, out = ctx.decompress(z, cap)
-            if code != -4:  # BZ2HIP_E_CAP: a block did not fit
+            if code != -4 or cap >= cap_max:  # BZ2HIP_E_CAP: a block did not fit
                 return code, out
-            cap *= 4
+            cap = min(cap * 4, cap_max)
 
     try:
         if not a.files:

@@ -90,14 +90,14 @@ def load():
     L.bz2hip_rle1_split.restype = C.c_int
     L.bz2hip_rle1_split.argtypes = [vp, vp, sz, C.c_int, C.c_uint32, u32p, vp, vp, vp, vp, vp]
     L.bz2hip_bwt.restype = C.c_int
-    L.bz2hip_bwt.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp]
+    L.bz2hip_bwt.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, C.c_uint32]
     L.bz2hip_mtf_rle2.restype = C.c_int
     L.bz2hip_mtf_rle2.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp]
     L.bz2hip_huffman.restype = C.c_int
     L.bz2hip_huffman.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp,
                                  C.c_uint32, vp]
     L.bz2hip_block_compress.restype = C.c_int
-    L.bz2hip_block_compress.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, sz, vp]
+    L.bz2hip_block_compress.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, sz, vp, C.c_uint32]
     L.bz2hip_profile_reset.restype = C.c_int
     L.bz2hip_profile_reset.argtypes = [vp]
     L.bz2hip_profile_get.restype = C.c_int
@@ -366,7 +366,7 @@ class Context:
         k = nb.value
         return starts[:k], [rle[b, : rlen[b]].copy() for b in range(k)], present[:k], crc[:k]
 
-    def bwt(self, blocks):
+    def bwt(self, blocks, declared_block_size=0):
         """blocks: list of uint8 arrays -> list of (bwt, orig, rounds)"""
         count = len(blocks)
         stride = max(max(len(b) for b in blocks), 1)
@@ -378,7 +378,8 @@ class Context:
         out = np.zeros((count, stride), dtype=np.uint8)
         orig = np.zeros(count, dtype=np.uint32)
         rounds = np.zeros(count, dtype=np.uint32)
-        self._chk(self.L.bz2hip_bwt(self.h, _p(T), _p(n), count, stride, _p(out), _p(orig), _p(rounds)))
+        self._chk(self.L.bz2hip_bwt(self.h, _p(T), _p(n), count, stride, _p(out), _p(orig), _p(rounds),
+                                    declared_block_size))
         return [(out[i, : n[i]].copy(), int(orig[i]), int(rounds[i])) for i in range(count)]
 
     def mtf_rle2(self, bwts, presents):
@@ -417,7 +418,7 @@ class Context:
                                         _p(nt), _p(lengths), _p(sel), ss, _p(ns)))
         return [(int(nt[i]), lengths[i].copy(), sel[i, : ns[i]].copy()) for i in range(count)]
 
-    def block_compress(self, blocks, presents, crcs):
+    def block_compress(self, blocks, presents, crcs, declared_block_size=0):
         count = len(blocks)
         stride = max(len(b) for b in blocks)
         T = np.zeros((count, stride), dtype=np.uint8)
@@ -431,7 +432,7 @@ class Context:
         bits = np.zeros((count, bstride), dtype=np.uint8)
         nbits = np.zeros(count, dtype=np.uint64)
         self._chk(self.L.bz2hip_block_compress(self.h, _p(T), _p(n), count, stride, _p(pres),
-                                               _p(crc), _p(bits), bstride, _p(nbits)))
+                                               _p(crc), _p(bits), bstride, _p(nbits), declared_block_size))
         return [(bits[i, : (int(nbits[i]) + 7) // 8].copy(), int(nbits[i])) for i in range(count)]
 
     # ---- profiling

@@ -20,18 +20,6 @@
 // has succeeded, and a failed allocation leaves an empty batch (NB = 0) that the next call
 // rebuilds.  The same carving serves the allocation-free entry point (region = the static
 // scratch array, bz2hip_compress_device_noalloc below).
-struct Carver {
-    u8 *base;        // nullptr: count only
-    size_t off = 0;
-    template <typename T>
-    T *get(size_t count) {
-        const size_t bytes = (std::max<size_t>(count * sizeof(T), 256) + 255) & ~(size_t)255;
-        T *p = base ? (T *)(base + off) : nullptr;
-        off += bytes;
-        return p;
-    }
-};
-
 static u32 slot_elems(int level) {
     return (u32)(((size_t)level * 100000 + 8 + RTILE - 1) / RTILE * RTILE);
 }
@@ -292,6 +280,7 @@ extern "C" int bz2hip_create(bz2hip_ctx **out, const bz2hip_opts *opts) {
     c->r0bits = (u32)env_int("BZ2HIP_R0BITS", 40);
     c->r0_sweeps = (u32)std::min(16, std::max(1, env_int("BZ2HIP_RSWEEPS", 2)));
     c->stream_chunk = (size_t)std::max(1, env_int("BZ2HIP_STREAM_CHUNK_MIB", (int)(STREAM_CHUNK >> 20))) << 20;
+    if (int m = env_int("BZ2HIP_DEC_PASS_MIB", 0)) c->dec_pass_bytes = (u64)std::max(1, m) << 20;
     try {
         k1_init_tables(c);
         HIPCHK(hipEventCreateWithFlags(&c->crc_done, hipEventDisableTiming));
@@ -335,6 +324,7 @@ extern "C" void bz2hip_destroy(bz2hip_ctx *c) {
     c->peers.clear();
     (void)hipSetDevice(c->device);
     if (c->d_shift) (void)hipFree(c->d_shift);
+    if (c->dec_region) (void)hipFree(c->dec_region);
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamSynchronize(c->stream_other);
     dfree_all(c);
@@ -1282,14 +1272,27 @@ static int level_for_maxn(u32 maxn) {
     return level;
 }
 
+// declared block size (what the reference's caller sized `SA` for: blockSize + 1 ints,
+// S/BZip2BlockCompressor.swift:318) -> level; 0 = the smallest level that holds the longest block
+static int level_for_declared(u32 declared, u32 maxn, int *level) {
+    if (declared == 0) { *level = level_for_maxn(maxn); return BZ2HIP_OK; }
+    if (declared % 100000u != 0 || declared < 100000u || declared > 900000u || maxn > declared) return BZ2HIP_E_PARAM;
+    *level = (int)(declared / 100000u);
+    return BZ2HIP_OK;
+}
+
 extern "C" int bz2hip_bwt(bz2hip_ctx *c, const uint8_t *blocks, const uint32_t *n, uint32_t count,
-                          uint32_t stride, uint8_t *bwt, uint32_t *orig, uint32_t *rounds) {
+                          uint32_t stride, uint8_t *bwt, uint32_t *orig, uint32_t *rounds,
+                          uint32_t declared_block_size) {
     return guarded(c, [&]() -> int {
         if (!blocks || !n || !bwt || !orig) return fail(c, BZ2HIP_E_PARAM, "null pointer");
         u32 maxn = 0;
         for (u32 b = 0; b < count; b++) maxn = std::max(maxn, n[b]);
         if (maxn > 900000 || maxn > stride) return fail(c, BZ2HIP_E_PARAM, "block longer than 900000 or stride");
-        ensure_batch(c, level_for_maxn(maxn), (int)count);
+        int blevel = 0;
+        if (level_for_declared(declared_block_size, maxn, &blevel) != BZ2HIP_OK)
+            return fail(c, BZ2HIP_E_PARAM, "declared_block_size must be 0 or level * 100000 and hold every block");
+        ensure_batch(c, blevel, (int)count);
         Batch &B = c->batch;
         for (u32 b0 = 0; b0 < count; b0 += (u32)B.NB) {
             int nb = (int)std::min<u32>((u32)B.NB, count - b0);
@@ -1381,7 +1384,7 @@ extern "C" int bz2hip_huffman(bz2hip_ctx *c, const uint16_t *mtf, const uint32_t
 extern "C" int bz2hip_block_compress(bz2hip_ctx *c, const uint8_t *rle_blocks, const uint32_t *n,
                                      uint32_t count, uint32_t stride, const uint8_t *present,
                                      const uint32_t *crc, uint8_t *bits, size_t bits_stride,
-                                     uint64_t *nbits) {
+                                     uint64_t *nbits, uint32_t declared_block_size) {
     return guarded(c, [&]() -> int {
         if (!rle_blocks || !n || !present || !crc || !bits || !nbits)
             return fail(c, BZ2HIP_E_PARAM, "null pointer");
@@ -1392,7 +1395,10 @@ extern "C" int bz2hip_block_compress(bz2hip_ctx *c, const uint8_t *rle_blocks, c
             maxn = std::max(maxn, n[b]);
         }
         if (maxn > 900000 || maxn > stride) return fail(c, BZ2HIP_E_PARAM, "block longer than 900000 or stride");
-        ensure_batch(c, level_for_maxn(maxn), (int)count);
+        int blevel = 0;
+        if (level_for_declared(declared_block_size, maxn, &blevel) != BZ2HIP_OK)
+            return fail(c, BZ2HIP_E_PARAM, "declared_block_size must be 0 or level * 100000 and hold every block");
+        ensure_batch(c, blevel, (int)count);
         Batch &B = c->batch;
         ensure_staging(c, 0, (size_t)B.NB * bits_stride);
         for (u32 b0 = 0; b0 < count; b0 += (u32)B.NB) {
@@ -1422,38 +1428,52 @@ extern "C" int bz2hip_rle1_split(bz2hip_ctx *c, const uint8_t *in, size_t n, int
     return guarded(c, [&]() -> int {
         if (level < 1 || level > 9) return fail(c, BZ2HIP_E_PARAM, "Invalid BZip2 block size");
         if (!n_blocks || !starts || (n && !in)) return fail(c, BZ2HIP_E_PARAM, "null pointer");
-        if (n > WMAX) return fail(c, BZ2HIP_E_PARAM, "input larger than one window (1 GiB)");
         *n_blocks = 0;
         if (n == 0) return BZ2HIP_OK;
         const u32 bs = (u32)level * 100000u;
         const size_t rstride = (size_t)bs + 8;
-        ensure_staging(c, n, 0);
-        HIPCHK(hipMemcpyAsync(c->h_in, in, n, hipMemcpyHostToDevice, c->stream));
-        ensure_batch(c, level, (int)std::min<size_t>(n / (bs - 4) + 1, 1u << 20));
-        ensure_window(c, n, level);
+        const bool emit = rle && rle_len && present && crc;
+        // windows of at most WMAX bytes, as the whole-stream path cuts them: a block that ends at
+        // the end of a window that is not the last is dropped there and begins the next window
+        size_t pos = 0;
+        u32 total = 0;
         std::vector<u32> hs;
-        u32 cnt = run_split(c, c->h_in, (u32)n, level, c->w_rs, c->w_P, c->w_agg1, c->w_agg2,
-                            c->w_starts, c->w_maxblocks, hs);
-        if (cnt > max_blocks) return fail(c, BZ2HIP_E_CAP, "more blocks than max_blocks");
-        *n_blocks = cnt;
-        for (u32 b = 0; b < cnt; b++) starts[b] = hs[b];
-        if (!rle || !rle_len || !present || !crc) return BZ2HIP_OK;
-        Batch &B = c->batch;
-        for (u32 b0 = 0; b0 < cnt; b0 += (u32)B.NB) {
-            int nb = (int)std::min<u32>((u32)B.NB, cnt - b0);
-            u32 max_in = 0;
-            for (int b = 0; b < nb; b++) max_in = std::max(max_in, hs[b0 + b + 1] - hs[b0 + b]);
-            run_rle1_emit(c, c->h_in, c->w_rs, c->w_starts, b0, nb, max_in, c->w_eagg, c->w_ETPB);
-            HIPCHK(hipStreamSynchronize(c->stream));
-            HIPCHK(hipMemcpy2D(rle + (size_t)b0 * rstride, rstride, B.T, B.S, bs, nb, hipMemcpyDeviceToHost));
-            HIPCHK(hipMemcpy(rle_len + b0, B.n, nb * sizeof(u32), hipMemcpyDeviceToHost));
-            HIPCHK(hipMemcpy(crc + b0, B.crc, nb * sizeof(u32), hipMemcpyDeviceToHost));
-            std::vector<u32> pw((size_t)nb * 8);
-            HIPCHK(hipMemcpy(pw.data(), B.present, pw.size() * 4, hipMemcpyDeviceToHost));
-            for (int b = 0; b < nb; b++)
-                for (int v = 0; v < 256; v++)
-                    present[((size_t)b0 + b) * 256 + v] = (pw[(size_t)b * 8 + (v >> 5)] >> (v & 31)) & 1u;
+        while (pos < n) {
+            const size_t wlen = std::min<size_t>(n - pos, WMAX);
+            const bool last_window = (pos + wlen == n);
+            ensure_staging(c, wlen, 0);
+            HIPCHK(hipMemcpyAsync(c->h_in, in + pos, wlen, hipMemcpyHostToDevice, c->stream));
+            prepare_window(c, c->h_in, wlen, level);
+            u32 cnt = run_chain(c, (u32)wlen, level, c->w_rs, c->w_P, c->w_agg2, c->w_starts, c->w_maxblocks, 0,
+                                (u32)wlen, hs);
+            u32 usable = cnt;
+            if (!last_window && cnt > 0 && hs[cnt] == (u32)wlen) usable = cnt - 1;
+            if (usable == 0) throw HipError(BZ2HIP_E_HIP, "window holds no complete block");
+            if (total + usable > max_blocks) return fail(c, BZ2HIP_E_CAP, "more blocks than max_blocks");
+            for (u32 b = 0; b < usable; b++) starts[total + b] = pos + hs[b];
+            if (emit) {
+                Batch &B = c->batch;
+                for (u32 b0 = 0; b0 < usable; b0 += (u32)B.NB) {
+                    int nb = (int)std::min<u32>((u32)B.NB, usable - b0);
+                    u32 max_in = 0;
+                    for (int b = 0; b < nb; b++) max_in = std::max(max_in, hs[b0 + b + 1] - hs[b0 + b]);
+                    run_rle1_emit(c, c->h_in, c->w_rs, c->w_starts, b0, nb, max_in, c->w_eagg, c->w_ETPB);
+                    HIPCHK(hipStreamSynchronize(c->stream));
+                    const size_t o = (size_t)total + b0;
+                    HIPCHK(hipMemcpy2D(rle + o * rstride, rstride, B.T, B.S, bs, nb, hipMemcpyDeviceToHost));
+                    HIPCHK(hipMemcpy(rle_len + o, B.n, nb * sizeof(u32), hipMemcpyDeviceToHost));
+                    HIPCHK(hipMemcpy(crc + o, B.crc, nb * sizeof(u32), hipMemcpyDeviceToHost));
+                    std::vector<u32> pw((size_t)nb * 8);
+                    HIPCHK(hipMemcpy(pw.data(), B.present, pw.size() * 4, hipMemcpyDeviceToHost));
+                    for (int b = 0; b < nb; b++)
+                        for (int v = 0; v < 256; v++)
+                            present[(o + b) * 256 + v] = (pw[(size_t)b * 8 + (v >> 5)] >> (v & 31)) & 1u;
+                }
+            }
+            total += usable;
+            pos += hs[usable];
         }
+        *n_blocks = total;
         if (c->profile) c->prof_collect();
         return BZ2HIP_OK;
     });

@@ -24,6 +24,20 @@ struct HipError : std::runtime_error {
         }                                                                                    \
     } while (0)
 
+// Carves arrays (256-byte aligned each) out of one device region; base == nullptr: count only.
+struct Carver {
+    u8 *base;        // nullptr: count only
+    size_t off = 0;
+    template <typename T>
+    T *get(size_t count) {
+        const size_t bytes = (std::max<size_t>(count * sizeof(T), 256) + 255) & ~(size_t)255;
+        T *p = base ? (T *)(base + off) : nullptr;
+        off += bytes;
+        return p;
+    }
+};
+
+
 // Device workspace for one batch of up to NB blocks laid out at stride S elements.
 struct Batch {
     int NB = 0;      // capacity (blocks)
@@ -115,6 +129,10 @@ struct bz2hip_ctx {
     u32 r0bits = 40;         // BZ2HIP_R0BITS
     u32 r0_sweeps = 2;       // BZ2HIP_RSWEEPS
     size_t stream_chunk = (size_t)64 << 20; // BZ2HIP_STREAM_CHUNK_MIB: streaming flush threshold per GPU
+    u64 dec_pass_bytes = 0xfffffff0ull;     // BZ2HIP_DEC_PASS_MIB (tests): decoded bytes written per pass (u32 offsets)
+    // decoder workspace, kept between calls (one region, grown on demand)
+    void *dec_region = nullptr;
+    size_t dec_region_cap = 0;
     bool fixed_ws = false;   // allocation-free call in progress: workspace carved from the static scratch
     u8 *scratch = nullptr;   // this device's address of the static scratch array (api.hip)
     hipEvent_t crc_done = nullptr;

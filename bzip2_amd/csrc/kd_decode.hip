@@ -856,16 +856,6 @@ __global__ __launch_bounds__(64) void kd_unrle_write(const u8 *__restrict__ tt,
 
 // ------------------------------------------------------------------ host driver
 namespace {
-struct DevBuf {
-    std::vector<void *> v;
-    ~DevBuf() { for (void *p : v) (void)hipFree(p); }
-    template <typename T> T *get(size_t count) {
-        void *p = nullptr;
-        HIPCHK(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
-        v.push_back(p);
-        return (T *)p;
-    }
-};
 int map_status(u32 s) {
     switch (s) {
     case KS_INSUFFICIENT: return BZ2HIP_E_INSUFFICIENT;
@@ -914,11 +904,51 @@ int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size
     const u32 block_size = (u32)level * 100000u;
     const u32 S = ((block_size + 64 + RTILE - 1) / RTILE) * RTILE;
 
-    DevBuf D;
     // a block is at least ~ 130 bits long: the scan cannot find more real blocks than this
     const u32 cand_cap = (u32)std::min<u64>(nbytes / 8 + 16, 1u << 24);
-    u64 *d_cand = D.get<u64>(cand_cap);
-    u32 *d_ncand = D.get<u32>(4);
+    // The workspace is one region kept in the context between calls (grown on demand): candidates
+    // first (their number sets the batch size), then the batch arrays.
+    const u32 RS = (block_size + KD_RULER - 1) / KD_RULER + 2;
+    const u32 ETPB_MAX = (u32)(((u64)block_size * 52 + 4095) / 4096 + 2);
+    u64 *d_cand = nullptr;
+    u32 *d_ncand = nullptr;
+    u8 *d_bwt = nullptr, *d_tt = nullptr;
+    u32 *d_meta = nullptr, *d_slot = nullptr, *d_n = nullptr, *d_orig = nullptr, *d_base = nullptr, *d_merged = nullptr;
+    uint2 *d_rinfo = nullptr, *d_visits = nullptr;
+    u32 *d_nvis = nullptr, *d_cyc = nullptr, *d_outlen = nullptr, *d_flags = nullptr, *d_outbase = nullptr, *d_crc = nullptr;
+    u32 *d_segstart = nullptr, *d_segres = nullptr, *d_segin = nullptr, *d_cagg = nullptr;
+    auto layout = [&](u8 *base, u32 NB) -> size_t {
+        Carver A{base};
+        d_cand = A.get<u64>(cand_cap);
+        d_ncand = A.get<u32>(4);
+        d_bwt = A.get<u8>((size_t)NB * S);
+        d_tt = A.get<u8>((size_t)NB * S);
+        d_meta = A.get<u32>((size_t)NB * KM_WORDS);
+        d_slot = A.get<u32>(NB); d_n = A.get<u32>(NB); d_orig = A.get<u32>(NB);
+        d_base = A.get<u32>((size_t)NB * KD_MPARTS * 256);
+        d_merged = A.get<u32>((size_t)NB * S);
+        d_rinfo = A.get<uint2>((size_t)NB * RS); d_visits = A.get<uint2>((size_t)NB * RS);
+        d_nvis = A.get<u32>(NB); d_cyc = A.get<u32>(NB);
+        d_outlen = A.get<u32>(NB); d_flags = A.get<u32>(NB); d_outbase = A.get<u32>(NB + 1);
+        d_crc = A.get<u32>(NB);
+        d_segstart = A.get<u32>((size_t)NB * (KD_SEGS + 1)); d_segres = A.get<u32>((size_t)NB * KD_SEGS * 4);
+        d_segin = A.get<u32>((size_t)NB * KD_SEGS * 2);
+        d_cagg = A.get<u32>((size_t)NB * ETPB_MAX);
+        return A.off;
+    };
+    auto ensure = [&](u32 NB) {
+        const size_t need = layout(nullptr, NB);
+        if (c->dec_region_cap < need) {
+            c->dec_region_cap = 0;
+            if (c->dec_region) (void)hipFree(c->dec_region);
+            c->dec_region = nullptr;
+            HIPCHK(hipMalloc(&c->dec_region, need));
+            c->dec_region_cap = need;
+        }
+        layout((u8 *)c->dec_region, NB);
+    };
+    ensure(1); // the candidate list sits at the front of the region: it survives the regrowth below only
+               // through the host copy, which is uploaded again once the batch size is known
     HIPCHK(hipMemsetAsync(d_ncand, 0, 16, st));
     kd_scan_magic<<<(u32)((nbytes + 255) / 256), 256, 0, st>>>(d_in, nbytes, d_cand, d_ncand, cand_cap);
     KCHECK();
@@ -931,24 +961,11 @@ int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size
         HIPCHK(hipMemcpyAsync(cand.data(), d_cand, ncand * sizeof(u64), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         std::sort(cand.begin(), cand.end());
-        HIPCHK(hipMemcpyAsync(d_cand, cand.data(), ncand * sizeof(u64), hipMemcpyHostToDevice, st));
     }
     // batch workspace
     const u32 NB = std::max(1u, std::min<u32>(ncand, KD_BATCH));
-    const u32 RS = (block_size + KD_RULER - 1) / KD_RULER + 2;
-    u8 *d_bwt = D.get<u8>((size_t)NB * S), *d_tt = D.get<u8>((size_t)NB * S);
-    u32 *d_meta = D.get<u32>((size_t)NB * KM_WORDS);
-    u32 *d_slot = D.get<u32>(NB), *d_n = D.get<u32>(NB), *d_orig = D.get<u32>(NB);
-    u32 *d_base = D.get<u32>((size_t)NB * KD_MPARTS * 256);
-    u32 *d_merged = D.get<u32>((size_t)NB * S);
-    uint2 *d_rinfo = D.get<uint2>((size_t)NB * RS), *d_visits = D.get<uint2>((size_t)NB * RS);
-    u32 *d_nvis = D.get<u32>(NB), *d_cyc = D.get<u32>(NB);
-    u32 *d_outlen = D.get<u32>(NB), *d_flags = D.get<u32>(NB), *d_outbase = D.get<u32>(NB + 1);
-    u32 *d_crc = D.get<u32>(NB);
-    u32 *d_segstart = D.get<u32>((size_t)NB * (KD_SEGS + 1)), *d_segres = D.get<u32>((size_t)NB * KD_SEGS * 4);
-    u32 *d_segin = D.get<u32>((size_t)NB * KD_SEGS * 2);
-    u32 *d_cagg = nullptr;
-    size_t cagg_cap = 0;
+    ensure(NB);
+    if (ncand) HIPCHK(hipMemcpyAsync(d_cand, cand.data(), ncand * sizeof(u64), hipMemcpyHostToDevice, st));
     std::vector<u32> meta((size_t)NB * KM_WORDS);
 
     u32 stream_crc = 0, nblocks = 0;
@@ -1026,54 +1043,61 @@ int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size
             // The reference stops at the first block whose CRC fails, so a damaged block that decodes
             // to something huge must not turn into a capacity error of a later one: the CRCs of the
             // blocks before the stop are compared first, below.
-            u32 good = nb; // blocks [0, good) are expanded
+            // Output offsets inside one pass are 32-bit: a chain that expands to more than that (zeros:
+            // ~46 MB per -9 block) is written in several passes over [k0, k1).
             int rc2 = BZ2HIP_OK;
             const char *msg2 = "";
-            std::vector<u32> h_base(1, 0);
-            u64 total = 0;
-            u32 maxlen = 0;
-            for (u32 k = 0; k < nb; k++) {
-                if (k == first_bad_ptr) { good = k; rc2 = BZ2HIP_E_START_PTR; msg2 = "BZip2 start pointer invalid"; break; }
-                if (out_total + total + h_outlen[k] > cap || total + h_outlen[k] > 0xfffffff0ull || (h_flags[k] & 2u)) {
-                    good = k;
-                    rc2 = BZ2HIP_E_CAP;
-                    msg2 = "output buffer too small";
-                    break;
-                }
-                if (h_flags[k] & 1u) { good = k; rc2 = BZ2HIP_E_FORMAT; msg2 = "block ends where a repeat count is due"; break; }
-                total += h_outlen[k];
-                maxlen = std::max(maxlen, h_outlen[k]);
-                h_base.push_back((u32)total);
-            }
-            if (good) {
-                u8 *o = d_out + out_total;
-                HIPCHK(hipMemcpyAsync(d_outbase, h_base.data(), (good + 1) * 4, hipMemcpyHostToDevice, st));
-                kd_unrle_write<<<dim3(KD_SEGS, good), 64, 0, st>>>(d_tt, d_n, S, d_segstart, d_segin, d_outbase, o);
-                KCHECK();
-                const u32 ETPB = (maxlen + 4095) / 4096 + 1;
-                if ((size_t)good * ETPB > cagg_cap) {
-                    cagg_cap = (size_t)good * ETPB;
-                    d_cagg = D.get<u32>(cagg_cap);
-                }
-                run_crc_blocks(c, o, d_outbase, (int)good, maxlen, d_cagg, ETPB, d_crc);
-                std::vector<u32> got(good);
-                HIPCHK(hipMemcpyAsync(got.data(), d_crc, good * 4, hipMemcpyDeviceToHost, st));
-                HIPCHK(hipStreamSynchronize(st));
-                for (u32 k = 0; k < good; k++) {
-                    if (got[k] != h_crc[k]) {
-                        // the block's bytes are out before its CRC is compared (S/BZip2InputStream.swift:209-212)
-                        *produced = out_total + h_base[k + 1];
-                        if (blocks_out) *blocks_out = nblocks + k + 1;
-                        c->err = "BZip2 block CRC error";
-                        return BZ2HIP_E_BLOCK_CRC;
+            u32 k0 = 0;
+            while (k0 < nb && rc2 == BZ2HIP_OK) {
+                std::vector<u32> h_base(1, 0);
+                u64 total = 0;
+                u32 maxlen = 0, k1 = k0;
+                for (u32 k = k0; k < nb; k++) {
+                    if (k == first_bad_ptr) { rc2 = BZ2HIP_E_START_PTR; msg2 = "BZip2 start pointer invalid"; break; }
+                    if (out_total + total + h_outlen[k] > cap || (h_flags[k] & 2u)) {
+                        rc2 = BZ2HIP_E_CAP;
+                        msg2 = "output buffer too small";
+                        break;
                     }
-                    stream_crc = ((stream_crc << 1) | (stream_crc >> 31)) ^ h_crc[k];
+                    if (k > k0 && total + h_outlen[k] > c->dec_pass_bytes) break; // next pass
+                    if (h_flags[k] & 1u) { rc2 = BZ2HIP_E_FORMAT; msg2 = "block ends where a repeat count is due"; break; }
+                    total += h_outlen[k];
+                    maxlen = std::max(maxlen, h_outlen[k]);
+                    h_base.push_back((u32)total);
+                    k1 = k + 1;
                 }
+                const u32 good = k1 - k0; // blocks [k0, k1) are expanded in this pass
+                if (good) {
+                    u8 *o = d_out + out_total;
+                    HIPCHK(hipMemcpyAsync(d_outbase, h_base.data(), (good + 1) * 4, hipMemcpyHostToDevice, st));
+                    kd_unrle_write<<<dim3(KD_SEGS, good), 64, 0, st>>>(
+                        d_tt + (size_t)k0 * S, d_n + k0, S, d_segstart + (size_t)k0 * (KD_SEGS + 1),
+                        d_segin + (size_t)k0 * KD_SEGS * 2, d_outbase, o);
+                    KCHECK();
+                    const u32 ETPB = (maxlen + 4095) / 4096 + 1;
+                    if (ETPB > ETPB_MAX) throw HipError(BZ2HIP_E_HIP, "internal: decoded block longer than 52 x block size");
+                    run_crc_blocks(c, o, d_outbase, (int)good, maxlen, d_cagg, ETPB, d_crc);
+                    std::vector<u32> got(good);
+                    HIPCHK(hipMemcpyAsync(got.data(), d_crc, good * 4, hipMemcpyDeviceToHost, st));
+                    HIPCHK(hipStreamSynchronize(st));
+                    for (u32 k = 0; k < good; k++) {
+                        if (got[k] != h_crc[k0 + k]) {
+                            // the block's bytes are out before its CRC is compared (S/BZip2InputStream.swift:209-212)
+                            *produced = out_total + h_base[k + 1];
+                            if (blocks_out) *blocks_out = nblocks + k + 1;
+                            c->err = "BZip2 block CRC error";
+                            return BZ2HIP_E_BLOCK_CRC;
+                        }
+                        stream_crc = ((stream_crc << 1) | (stream_crc >> 31)) ^ h_crc[k0 + k];
+                    }
+                }
+                out_total += (size_t)total;
+                nblocks += good;
+                *produced = out_total;
+                if (blocks_out) *blocks_out = nblocks;
+                k0 = k1;
+                if (!good) break;
             }
-            out_total += (size_t)total;
-            nblocks += good;
-            *produced = out_total;
-            if (blocks_out) *blocks_out = nblocks;
             if (rc2 != BZ2HIP_OK) { c->err = msg2; return rc2; }
         }
         if (rc_huff != BZ2HIP_OK) { c->err = "block could not be decoded"; return rc_huff; }

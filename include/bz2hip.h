@@ -180,16 +180,22 @@ size_t bz2hip_stream_pending(const bz2hip_ctx *ctx);
 
 /* Block boundaries + RLE1 + CRC: BZip2BlockCompressor.write/writeRun
  * (S/BZip2BlockCompressor.swift:151-252) and BZip2CRC32 (S/BZip2CRC32.swift:76-105).
- * starts[b] = input offset of block b; rle (stride level*100000+8) receives the RLE1 blocks. */
+ * starts[b] = input offset of block b; rle (stride level*100000+8) receives the RLE1 blocks
+ * (rle .. crc may all be NULL: boundaries only).  Any input length: the input is scanned in
+ * windows of 1 GiB. */
 int bz2hip_rle1_split(bz2hip_ctx *ctx, const uint8_t *in, size_t n, int level,
                       uint32_t max_blocks, uint32_t *n_blocks, uint64_t *starts,
                       uint8_t *rle, uint32_t *rle_len, uint8_t *present /*[b][256]*/,
                       uint32_t *crc);
 
 /* BZip2DivSufSort(T, SA, n).bwt()  S/BZip2DivSufSort.swift:3487-3518: last column of the sorted
- * cyclic rotations and the origin pointer.  rounds (optional) = doubling rounds executed. */
+ * cyclic rotations and the origin pointer.  rounds (optional) = doubling rounds executed.
+ * declared_block_size = the block size the caller's SA array was sized for (blockSize + 1 ints,
+ * S/BZip2BlockCompressor.swift:318; level * 100000): the origin pointer of a periodic block
+ * depends on it.  0 = the smallest level that holds the longest block. */
 int bz2hip_bwt(bz2hip_ctx *ctx, const uint8_t *blocks, const uint32_t *n, uint32_t count,
-               uint32_t stride, uint8_t *bwt, uint32_t *orig, uint32_t *rounds);
+               uint32_t stride, uint8_t *bwt, uint32_t *orig, uint32_t *rounds,
+               uint32_t declared_block_size);
 
 /* BZip2MTFAndRLE2StageEncoder(bwt, n, present).encode() + getters
  * (S/BZip2MTFAndRLE2StageEncoder.swift:43-163).  mtf has stride+2 elements per block. */
@@ -212,7 +218,7 @@ int bz2hip_huffman(bz2hip_ctx *ctx, const uint16_t *mtf, const uint32_t *mtf_len
 int bz2hip_block_compress(bz2hip_ctx *ctx, const uint8_t *rle_blocks, const uint32_t *n,
                           uint32_t count, uint32_t stride, const uint8_t *present,
                           const uint32_t *crc, uint8_t *bits, size_t bits_stride,
-                          uint64_t *nbits);
+                          uint64_t *nbits, uint32_t declared_block_size /* as in bz2hip_bwt */);
 
 /* ---- Decoder.  Replaces BZip2InputStream.read(...) over a whole stream
  * (S/BZip2InputStream.swift:91-128,154-242) and the classes under it (BZip2BlockDecompressor,

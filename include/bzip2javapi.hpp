@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <new>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -282,11 +283,17 @@ class BZip2InputStream : public java::io::InputStream {
         for (int b; (b = inputStream->read()) >= 0;) z.push_back((uint8_t)b);
         detail::Ctx ctx;
         size_t cap = z.size() * 8 + (1u << 20), got = 0;
-        for (;;) { // BZ2HIP_E_CAP: a block did not fit, try again with more room
-            decoded.assign(cap, 0);
+        // no stream expands by more than ~1.24 million (a block of 255-runs: 45.9 MB from ~37 bytes)
+        const size_t cap_max = z.size() * (size_t)1250000 + (1u << 20);
+        for (;;) { // BZ2HIP_E_CAP: a block did not fit, try again with more room (bounded)
+            try {
+                decoded.assign(cap, 0);
+            } catch (const std::bad_alloc &) {
+                throw BZip2Exception(BZip2Exception::IOException, "bz2hip: out of memory for the decoded stream");
+            }
             pending = bz2hip_decompress(ctx.h, z.data(), z.size(), decoded.data(), cap, &got);
-            if (pending != BZ2HIP_E_CAP) break;
-            cap *= 4;
+            if (pending != BZ2HIP_E_CAP || cap >= cap_max) break;
+            cap = std::min(cap * 4, cap_max);
         }
         decoded.resize(got);
         const char *t = text(pending);

@@ -127,3 +127,31 @@ def test_cli_roundtrip(tmp_path):
     assert src.read_bytes() == data and not (tmp_path / "sample.bin.bz2").exists()
     out = subprocess.run([sys.executable, "-m", "bzip2_amd", "-c"], input=data, capture_output=True, env=env, cwd=ROOT)
     assert out.returncode == 0 and bz2.decompress(out.stdout) == data
+
+
+def test_chain_longer_than_32bit_offsets_is_written_in_passes(orc):
+    """Output offsets inside one decoder pass are 32-bit; a chain that expands to more (zeros: 46 MB
+    per -9 block) is written in several passes.  The pass size is lowered here (2 MiB) so that a
+    30 MB stream of long runs needs many passes; the bytes and the error behaviour stay the same."""
+    import os
+    import bz2
+    import bzip2_amd
+    os.environ["BZ2HIP_DEC_PASS_MIB"] = "2"
+    try:
+        c = bzip2_amd.Context()
+    finally:
+        del os.environ["BZ2HIP_DEC_PASS_MIB"]
+    try:
+        rng = np.random.default_rng(8)
+        d = np.concatenate((np.zeros(9_000_000, dtype=np.uint8), rng.integers(0, 256, 700_000, dtype=np.uint8),
+                            np.repeat(rng.integers(0, 256, 80_000, dtype=np.uint8), 255)))
+        for level in (1, 9):
+            z = bz2.compress(d.tobytes(), level)
+            rc, out = c.decompress(z, d.size)
+            assert rc == 0 and out == d.tobytes(), level
+            # too small a buffer is still E_CAP with the blocks that fit delivered, as the oracle says
+            rc, out = c.decompress(z, 5_000_000)
+            orc_rc, orc_out, _ = orc.decompress(z, 5_000_000)
+            assert rc == -4 and rc == MAP[orc_rc] and out == orc_out, level
+    finally:
+        c.close()

@@ -461,3 +461,57 @@ def test_multi_device_context(orc):
             assert out == want3, devices
         finally:
             c.close()
+
+
+def test_stage_entry_points_take_the_declared_block_size(ctx, orc):
+    """bz2hip_bwt / bz2hip_block_compress: the origin pointer of a periodic block depends on the size
+    the reference's caller declared (SA has blockSize + 1 ints); it is an argument, not derived
+    from the block length."""
+    import bzip2_amd
+    rng = np.random.default_rng(21)
+    blocks = [np.tile(np.array([1, 0, 2], dtype=np.uint8), 900), np.tile(rng.integers(0, 4, 31, dtype=np.uint8), 3200),
+              np.tile(np.frombuffer(b"ab", dtype=np.uint8), 40000), rng.integers(0, 256, 5000, dtype=np.uint8)]
+    try:
+        for declared in (100000, 400000, 900000):
+            orc.set_block_size(declared)
+            res = ctx.bwt(blocks, declared)
+            for blk, (bw, orig, _) in zip(blocks, res):
+                ob, oo, per = orc.bwt(blk)
+                assert np.array_equal(ob, bw) and oo == orig, (declared, blk.size, per)
+    finally:
+        orc.set_block_size(0)
+    with pytest.raises(bzip2_amd.BZ2HipError) as e:
+        ctx.bwt(blocks, 150000)
+    assert e.value.code == -1
+    with pytest.raises(bzip2_amd.BZ2HipError):
+        ctx.bwt([np.zeros(200000, dtype=np.uint8)], 100000)  # block longer than the declared size
+
+
+def test_failed_allocation_leaves_the_context_usable():
+    """BZ2HIP_E_NOMEM must not poison the context: capacities are published only after the
+    workspace exists.  Most of the GPU's memory is taken by the test itself, a 1 GiB level-1 call
+    (10 738 block slots, ~45 GB) then fails cleanly, and the same context compresses afterwards."""
+    import bz2
+    import torch
+    import bzip2_amd
+    free, total = torch.cuda.mem_get_info()
+    c = bzip2_amd.Context(max_batch_blocks=20000)
+    n = 1 << 30
+    d_in = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    cap = c.L.bz2hip_compress_bound(n)
+    d_out = torch.empty(cap + 64, dtype=torch.uint8, device="cuda")
+    free, _ = torch.cuda.mem_get_info()
+    hog = torch.empty(max(free - (30 << 30), 1 << 20), dtype=torch.uint8, device="cuda")  # leave 30 GB
+    try:
+        with pytest.raises(bzip2_amd.BZ2HipError) as e:
+            c.compress_device(d_in.data_ptr(), n, 1, d_out.data_ptr(), cap)
+        assert e.value.code == -2
+        # same level, small input: must allocate a small batch and work (not reuse stale capacities)
+        small = corpus.text(250000, 5)
+        assert bz2.decompress(c.compress(small, 1)) == small.tobytes()
+        del hog
+        torch.cuda.empty_cache()
+        k = c.compress_device(d_in.data_ptr(), 64 << 20, 1, d_out.data_ptr(), cap)
+        assert bz2.decompress(d_out[:k].cpu().numpy().tobytes()) == bytes(64 << 20)
+    finally:
+        c.close()
