@@ -46,8 +46,8 @@ static size_t layout_batch(Batch &N, int level, int nb_blocks, u8 *base) {
     N.mS = A.get<u32>(nb); N.mL = A.get<u32>(nb); N.mSn = A.get<u32>(nb); N.mLn = A.get<u32>(nb);
     N.hcur = A.get<u32>(nb); N.huse = A.get<u32>(nb); N.state = A.get<u32>(nb);
     N.par = A.get<u32>(nb); N.leftg = A.get<u32>(nb);
-    N.tilehist = A.get<u32>(nb * N.TPB * 256);
-    N.digitbase = A.get<u32>(nb * 256);
+    N.tilehist = A.get<u32>(nb * N.TPB * 1024); // up to 1024 bins per tile (10-bit digits)
+    N.digitbase = A.get<u32>(nb * 1024);
     N.tileagg = A.get<u32>(nb * N.TPB * 4);
     N.pvote = A.get<u32>(nb * 8192 * 2);
     N.cand = A.get<u32>(nb * 2);
@@ -279,6 +279,8 @@ extern "C" int bz2hip_create(bz2hip_ctx **out, const bz2hip_opts *opts) {
     c->plain_mask = (u32)env_int("BZ2HIP_PLAIN", 2);
     c->r0bits = (u32)env_int("BZ2HIP_R0BITS", 40);
     c->r0_sweeps = (u32)std::min(16, std::max(1, env_int("BZ2HIP_RSWEEPS", 2)));
+    c->radix_bits = env_int("BZ2HIP_RADIX_BITS", 8) == 10 ? 10u : 8u;
+    c->radix_stage = env_int("BZ2HIP_RADIX_STAGE", 1) != 0;
     c->stream_chunk = (size_t)std::max(1, env_int("BZ2HIP_STREAM_CHUNK_MIB", (int)(STREAM_CHUNK >> 20))) << 20;
     if (int m = env_int("BZ2HIP_DEC_PASS_MIB", 0)) c->dec_pass_bytes = (u64)std::max(1, m) << 20;
     try {

@@ -138,7 +138,12 @@ __device__ __forceinline__ u64 r0_key(const R0Tile &L, u32 local, u32 i, u32 d0)
 }
 
 // ------------------------------------------------------------------ LSD radix pass (u64 words)
-template <bool FROM_T>
+// DB = digit bits (8 or 10), RB = bins.  Per pass: tile digit histogram -> per-block scan -> stable
+// scatter.  The scatter first orders the tile by digit in LDS (rank = bin start + wave offset +
+// rank inside the wave's bin, from wave64 ballots) and then stores it in that order: consecutive
+// lanes write consecutive addresses of one bin, so a wave store touches a handful of lines instead
+// of one line per lane (the stores were bound by L2 requests, not by bytes).
+template <bool FROM_T, int DB>
 __global__ __launch_bounds__(RT_THREADS) void k2_radix_hist(const u64 *__restrict__ key,
                                                             const u32 *__restrict__ cntArr,
                                                             const u32 *__restrict__ state,
@@ -146,14 +151,16 @@ __global__ __launch_bounds__(RT_THREADS) void k2_radix_hist(const u64 *__restric
                                                             u32 TPB, int shift, u32 gtiles, u32 gnb,
                                                             const u8 *__restrict__ T,
                                                             const u32 *__restrict__ present, u32 r0bits) {
+    constexpr u32 RB = 1u << DB;
     XCD_MAP(gtiles, gnb)
     const u32 b = bz_b;
     if (state[b] != ST_ACTIVE) return;
     const u32 n = cntArr[b];
     const u32 base = bz_t * RTILE;
     if (base >= n) return;
-    __shared__ u32 hist[256];
-    hist[threadIdx.x] = 0;
+    __shared__ u32 hist[RB];
+    for (u32 q = threadIdx.x; q < RB; q += RT_THREADS) hist[q] = 0;
+    u32 *th = tilehist + ((size_t)b * TPB + bz_t) * RB;
     if (FROM_T) {
         __shared__ R0Tile L;
         r0_tile_load(L, T, present, b, S, n, base);
@@ -162,10 +169,10 @@ __global__ __launch_bounds__(RT_THREADS) void k2_radix_hist(const u64 *__restric
         for (int k = 0; k < RT_ITEMS; k++) {
             const u32 local = k * RT_THREADS + threadIdx.x;
             if (base + local < n)
-                atomicAdd(&hist[(u32)(r0_key(L, local, base + local, d0) >> shift) & 255u], 1u);
+                atomicAdd(&hist[(u32)(r0_key(L, local, base + local, d0) >> shift) & (RB - 1u)], 1u);
         }
         __syncthreads();
-        tilehist[((size_t)b * TPB + bz_t) * 256 + threadIdx.x] = hist[threadIdx.x];
+        for (u32 q = threadIdx.x; q < RB; q += RT_THREADS) th[q] = hist[q];
         return;
     }
     __syncthreads();
@@ -180,41 +187,58 @@ __global__ __launch_bounds__(RT_THREADS) void k2_radix_hist(const u64 *__restric
 #pragma unroll
     for (int k = 0; k < RT_ITEMS / 2; k++) {
         const u32 i = base + 2 * (k * RT_THREADS + threadIdx.x);
-        if (i < n) atomicAdd(&hist[(u32)(vv[k].x >> shift) & 255u], 1u);
-        if (i + 1 < n) atomicAdd(&hist[(u32)(vv[k].y >> shift) & 255u], 1u);
+        if (i < n) atomicAdd(&hist[(u32)(vv[k].x >> shift) & (RB - 1u)], 1u);
+        if (i + 1 < n) atomicAdd(&hist[(u32)(vv[k].y >> shift) & (RB - 1u)], 1u);
     }
     __syncthreads();
-    tilehist[((size_t)b * TPB + bz_t) * 256 + threadIdx.x] = hist[threadIdx.x];
+    for (u32 q = threadIdx.x; q < RB; q += RT_THREADS) th[q] = hist[q];
 }
 
+template <int DB>
 __global__ __launch_bounds__(256) void k2_radix_scan(const u32 *__restrict__ cntArr,
                                                      const u32 *__restrict__ state,
                                                      u32 *__restrict__ tilehist,
                                                      u32 *__restrict__ digitbase, u32 TPB) {
+    constexpr u32 RB = 1u << DB;
+    constexpr int PER = RB / 256; // digits per thread (consecutive)
     const u32 b = blockIdx.x;
     if (state[b] != ST_ACTIVE) return;
     const u32 n = cntArr[b];
     const u32 tiles = (n + RTILE - 1) / RTILE;
     __shared__ u32 sm[8];
-    u32 *th = tilehist + (size_t)b * TPB * 256 + threadIdx.x;
-    u32 run = 0;
+    u32 run[PER];
+#pragma unroll
+    for (int q = 0; q < PER; q++) run[q] = 0;
     for (u32 t = 0; t < tiles; t++) {
-        u32 c = th[(size_t)t * 256];
-        th[(size_t)t * 256] = run;
-        run += c;
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            // digit = q * 256 + thread: coalesced over threads
+            u32 *th = tilehist + ((size_t)b * TPB + t) * RB + q * 256 + threadIdx.x;
+            u32 c = *th;
+            *th = run[q];
+            run[q] += c;
+        }
     }
-    u32 total;
-    u32 ex = block_excl_scan_add<256>(run, sm, &total);
-    digitbase[b * 256 + threadIdx.x] = ex;
+    // exclusive scan over digits in digit order: digit = q * 256 + thread
+    u32 carry = 0;
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        u32 total;
+        u32 ex = block_excl_scan_add<256>(run[q], sm, &total);
+        digitbase[b * RB + q * 256 + threadIdx.x] = carry + ex;
+        carry += total;
+        __syncthreads();
+    }
 }
 
-// Lanes holding the same 8-bit digit (stable ranking inside a wave).  Per bit: t = -bit (one
+// Lanes holding the same DB-bit digit (stable ranking inside a wave).  Per bit: t = -bit (one
 // v_bfe_i32), one ballot, and "lanes that differ from me in this bit" = ballot ^ t, OR-ed up;
 // the complement of the union is the match set.
-__device__ __forceinline__ u64 match8(u32 d, bool valid) {
+template <int DB>
+__device__ __forceinline__ u64 match_digit(u32 d, bool valid) {
     u32 acc_lo = 0, acc_hi = 0;
 #pragma unroll
-    for (int bit = 0; bit < 8; bit++) {
+    for (int bit = 0; bit < DB; bit++) {
         const int t = __builtin_amdgcn_sbfe((int)d, bit, 1); // 0 or -1
         const u64 bb = __ballot(t != 0);
         acc_lo |= (u32)bb ^ (u32)t;
@@ -224,22 +248,27 @@ __device__ __forceinline__ u64 match8(u32 d, bool valid) {
     return ~(((u64)acc_hi << 32) | (u64)acc_lo) & v;
 }
 
-template <bool FROM_T>
-__global__ __launch_bounds__(RT_THREADS) void k2_radix_scatter(
+template <bool FROM_T, int DB, bool STAGE>
+__global__ __launch_bounds__(RT_THREADS, 4) void k2_radix_scatter(
     const u64 *__restrict__ keyIn, u64 *__restrict__ keyOut, const u32 *__restrict__ cntArr,
     const u32 *__restrict__ state, const u32 *__restrict__ tilehist,
     const u32 *__restrict__ digitbase, u32 S, u32 TPB, int shift, u32 gtiles, u32 gnb,
     const u8 *__restrict__ T, const u32 *__restrict__ present, u32 r0bits) {
+    constexpr u32 RB = 1u << DB;
+    constexpr int PER = RB / 256;
     XCD_MAP(gtiles, gnb)
     const u32 b = bz_b;
     if (state[b] != ST_ACTIVE) return;
     const u32 n = cntArr[b];
     const u32 base = bz_t * RTILE;
     if (base >= n) return;
-    __shared__ u32 whist[4][256];
-    __shared__ u32 gofs[256];
+    __shared__ u32 whist[4][RB];   // per-wave bin counts -> exclusive offsets over waves
+    __shared__ u32 binstart[STAGE ? RB : 1];   // tile-local start of every bin
+    __shared__ u32 gofs[RB];                   // output slot of the tile's first element of every bin
+    __shared__ u64 stage[STAGE ? RTILE : 1];   // the tile ordered by digit
+    __shared__ u32 sm[8];
     const int w = wave_id(), lane = lane_id();
-    for (int q = threadIdx.x; q < 4 * 256; q += RT_THREADS) (&whist[0][0])[q] = 0;
+    for (int q = threadIdx.x; q < 4 * (int)RB; q += RT_THREADS) (&whist[0][0])[q] = 0;
     __shared__ R0Tile L;
     u32 d0 = 0;
     if (FROM_T) {
@@ -257,47 +286,89 @@ __global__ __launch_bounds__(RT_THREADS) void k2_radix_scatter(
     for (int k = 0; k < RT_ITEMS; k++) {
         const u32 i = base + w * (RTILE / 4) + k * 64 + lane;
         const u32 ic = i < n ? i : base; // base < n
-        keys[k] = FROM_T ? r0_key(L, ic - base, ic, d0) : __builtin_nontemporal_load(&kp[ic]);
+        keys[k] = FROM_T ? r0_key(L, ic - base, ic, d0) : kp[ic];
     }
+    // Ranking, in two loops so that nothing waits inside them: the leaders' LDS atomics (with
+    // return) of all 16 rows are issued back to back -- the LDS executes one wave's atomics in
+    // order, so the counts stay stable -- and the results are broadcast afterwards.
+    u32 oldv[RT_ITEMS];
 #pragma unroll
     for (int k = 0; k < RT_ITEMS; k++) {
         u32 i = base + w * (RTILE / 4) + k * 64 + lane;
         bool valid = i < n;
         u64 kk = valid ? keys[k] : 0;
         keys[k] = kk;
-        u32 d = (u32)(kk >> shift) & 255u;
-        u64 m = match8(d, valid);
-        u32 r = __popcll(m & lt);
-        u32 cnt = __popcll(m);
-        int leader = __ffsll((unsigned long long)m) - 1;
-        u32 old = 0;
-        if (valid && lane == leader) {
-            old = whist[w][d];
-            whist[w][d] = old + cnt;
-        }
-        old = __shfl(old, leader < 0 ? 0 : leader, 64);
-        lr[k] = old + r;
+        u32 d = (u32)(kk >> shift) & (RB - 1u);
+        u64 m = match_digit<DB>(d, valid);
+        const int leader = __ffsll((unsigned long long)m) - 1;
+        lr[k] = __popcll(m & lt) | ((u32)(leader < 0 ? 0 : leader) << 8); // rank in the match set | leader lane
+        oldv[k] = 0;
+        if (valid && lane == leader) oldv[k] = atomicAdd(&whist[w][d], (u32)__popcll(m));
     }
+#pragma unroll
+    for (int k = 0; k < RT_ITEMS; k++) lr[k] = (lr[k] & 255u) + __shfl(oldv[k], (int)(lr[k] >> 8), 64);
     __syncthreads();
     {
-        const u32 d = threadIdx.x;
-        u32 run = 0;
+        // per digit: exclusive offsets over the 4 waves, the tile's bin sizes -> bin starts
+        u32 tot[PER];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            u32 c = whist[q][d];
-            whist[q][d] = run;
-            run += c;
+        for (int q = 0; q < PER; q++) {
+            const u32 d = threadIdx.x * PER + q; // consecutive digits per thread: scan order
+            u32 run = 0;
+#pragma unroll
+            for (int ww = 0; ww < 4; ww++) {
+                u32 c = whist[ww][d];
+                whist[ww][d] = run;
+                run += c;
+            }
+            tot[q] = run;
+            gofs[d] = digitbase[b * RB + d] + tilehist[((size_t)b * TPB + bz_t) * RB + d];
         }
-        gofs[d] = digitbase[b * 256 + d] + tilehist[((size_t)b * TPB + bz_t) * 256 + d];
+        if (STAGE) {
+            u32 mine = 0;
+#pragma unroll
+            for (int q = 0; q < PER; q++) mine += tot[q];
+            u32 total;
+            u32 ex = block_excl_scan_add<256>(mine, sm, &total);
+#pragma unroll
+            for (int q = 0; q < PER; q++) {
+                binstart[threadIdx.x * PER + q] = ex;
+                ex += tot[q];
+            }
+        }
     }
     __syncthreads();
     u64 *ko = keyOut + (size_t)b * S;
+    if (!STAGE) {
+        // straight from the registers: a bin's elements of one wave row go to consecutive slots
+#pragma unroll
+        for (int k = 0; k < RT_ITEMS; k++) {
+            u32 i = base + w * (RTILE / 4) + k * 64 + lane;
+            if (i < n) {
+                u32 d = (u32)(keys[k] >> shift) & (RB - 1u);
+                ko[gofs[d] + whist[w][d] + lr[k]] = keys[k]; // (not nontemporal: L2 merges these into full lines)
+            }
+        }
+        return;
+    }
+    // the tile in digit order
 #pragma unroll
     for (int k = 0; k < RT_ITEMS; k++) {
         u32 i = base + w * (RTILE / 4) + k * 64 + lane;
         if (i < n) {
-            u32 d = (u32)(keys[k] >> shift) & 255u;
-            ko[gofs[d] + whist[w][d] + lr[k]] = keys[k]; // (not nontemporal: L2 merges these into full lines)
+            u32 d = (u32)(keys[k] >> shift) & (RB - 1u);
+            stage[binstart[d] + whist[w][d] + lr[k]] = keys[k];
+        }
+    }
+    __syncthreads();
+    const u32 cnt = min((u32)RTILE, n - base);
+#pragma unroll
+    for (int k = 0; k < RT_ITEMS; k++) {
+        const u32 j = k * RT_THREADS + threadIdx.x;
+        if (j < cnt) {
+            const u64 kk = stage[j];
+            const u32 d = (u32)(kk >> shift) & (RB - 1u);
+            ko[gofs[d] + (j - binstart[d])] = kk; // (not nontemporal: L2 completes the lines shared by two tiles)
         }
     }
 }
@@ -508,19 +579,23 @@ __device__ __forceinline__ void tile_emit(const u64 *buf, int cnt, const int (&c
             lRun += (u32)sm[4 + q];
         }
     }
-    // gather the preceding bytes of all finished rotations first (16 gathers in flight; the
-    // others read T[0]), then do the stores
+    // The BWT bytes of rotations that finish in a doubling round are NOT written here: a finished
+    // rotation's rank is its final sorted position, so one streaming pass at the end of the sort
+    // (k2_emit_bwt: bwt[rank[i]] = T[i - 1]) writes them all, instead of one random T gather per
+    // rotation here.  Only the k-fold ties of a periodic block (MODE_FINAL) are placed from the
+    // list, in list order: gather their preceding bytes first (16 in flight), then store.
     u8 tb[16];
+    if (MODE == MODE_FINAL) {
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int idx = w * 1024 + k * 64 + lane;
-        const int c = cls[k];
-        u32 a = 0;
-        if (c != CLS_NONE && (MODE == MODE_FINAL || c == CLS_SINGLE)) {
-            const u32 i = (u32)(BUFX(idx) & E_IMASK);
-            a = (i == 0) ? n - 1 : i - 1;
+        for (int k = 0; k < 16; k++) {
+            const int idx = w * 1024 + k * 64 + lane;
+            u32 a = 0;
+            if (cls[k] != CLS_NONE) {
+                const u32 i = (u32)(BUFX(idx) & E_IMASK);
+                a = (i == 0) ? n - 1 : i - 1;
+            }
+            tb[k] = T[a];
         }
-        tb[k] = T[a];
     }
 #pragma unroll
     for (int k = 0; k < 16; k++) {
@@ -532,7 +607,7 @@ __device__ __forceinline__ void tile_emit(const u64 *buf, int cnt, const int (&c
             i = (u32)(e_ & E_IMASK);
             // the first sub-group of a split group keeps its rank: no write
             if (MODE == MODE_ROUND0 ? (i >= rlo && i < rhi) : (MODE == MODE_NORMAL && ngrp[k] != (u32)(e_ >> 40))) rank[i] = ngrp[k];
-            if (MODE == MODE_FINAL || c == CLS_SINGLE) bwt[spos[k]] = tb[k];
+            if (MODE == MODE_FINAL) bwt[spos[k]] = tb[k];
         }
         if (MODE != MODE_FINAL) {
             u64 ms = __ballot(c == CLS_SMALL), ml = __ballot(c == CLS_LKEEP);
@@ -1463,6 +1538,39 @@ __global__ __launch_bounds__(RT_THREADS, 3) void k2_ssort(const u64 *slA, const 
     PH_MARK(4);
 }
 
+// ------------------------------------------------------------------ BWT bytes
+// bwt[rank[i]] = T[(i - 1) mod n] for every rotation: rank and T are streamed, the 1-byte stores
+// land in the block's n-byte BWT array, which stays in the XCD's L2 (XCD-aware mapping) until its
+// lines are complete.  Rotations still tied at the end (periodic block) all carry their group's
+// rank and the same preceding byte; MODE_FINAL then places them one per slot.
+__global__ __launch_bounds__(RT_THREADS) void k2_emit_bwt(const u32 *__restrict__ nArr,
+                                                          const u32 *__restrict__ rank,
+                                                          const u8 *__restrict__ T, u8 *__restrict__ bwt,
+                                                          u32 S, u32 gtiles, u32 gnb) {
+    XCD_MAP(gtiles, gnb)
+    const u32 b = bz_b;
+    const u32 n = nArr[b];
+    const u32 base = bz_t * RTILE;
+    if (base >= n) return;
+    const u32 *rk = rank + (size_t)b * S;
+    const u8 *t = T + (size_t)b * S;
+    u8 *o = bwt + (size_t)b * S;
+    u32 rv[RT_ITEMS];
+    u8 tv[RT_ITEMS];
+#pragma unroll
+    for (int k = 0; k < RT_ITEMS; k++) {
+        const u32 i = base + k * RT_THREADS + threadIdx.x;
+        const u32 ic = i < n ? i : base;
+        rv[k] = __builtin_nontemporal_load(&rk[ic]);
+        tv[k] = t[ic == 0 ? n - 1 : ic - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < RT_ITEMS; k++) {
+        const u32 i = base + k * RT_THREADS + threadIdx.x;
+        if (i < n) o[rv[k]] = tv[k];
+    }
+}
+
 // ------------------------------------------------------------------ finish
 __global__ void k2_finish(const u32 *__restrict__ nArr, const u32 *__restrict__ rank,
                           const u32 *__restrict__ mS, const u32 *__restrict__ mL,
@@ -1522,42 +1630,57 @@ void run_present(bz2hip_ctx *c, int nb, u32 maxn) {
 #define nbarg(nb, bit) ((c->plain_mask & (bit)) ? ((u32)(nb) | 0x80000000u) : (u32)(nb))
 
 // `from_T`: the first pass builds the round-0 keys from the block bytes instead of reading `a`
-static void radix_sort5(bz2hip_ctx *c, int nb, u32 maxcnt, const u32 *cntArr, u64 *a, u64 *bbuf,
-                        int passes = 5, bool from_T = false) {
+template <int DB, bool STG>
+static void radix_sort_db(bz2hip_ctx *c, int nb, u32 maxcnt, const u32 *cntArr, u64 *a, u64 *bbuf,
+                          int passes, bool from_T) {
     Batch &B = c->batch;
     const u32 tiles = (maxcnt + RTILE - 1) / RTILE;
     u64 *kin = a, *kout = bbuf;
     for (int p = 0; p < passes; p++) {
-        int shift = KEY_SHIFT + 8 * p;
+        int shift = KEY_SHIFT + DB * p;
         const bool ft = from_T && p == 0;
         {
             ProfScope ps(c, P_RADIX_HIST);
             if (ft)
-                k2_radix_hist<true><<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(
+                k2_radix_hist<true, DB><<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(
                     kin, cntArr, B.state, B.tilehist, B.S, B.TPB, shift, tiles, nbarg(nb, 8), B.T, B.present, c->r0bits);
             else
-                k2_radix_hist<false><<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(
+                k2_radix_hist<false, DB><<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(
                     kin, cntArr, B.state, B.tilehist, B.S, B.TPB, shift, tiles, nbarg(nb, 8), B.T, B.present, c->r0bits);
             KCHECK();
         }
         {
             ProfScope ps(c, P_RADIX_SCAN);
-            k2_radix_scan<<<nb, 256, 0, c->stream>>>(cntArr, B.state, B.tilehist, B.digitbase, B.TPB);
+            k2_radix_scan<DB><<<nb, 256, 0, c->stream>>>(cntArr, B.state, B.tilehist, B.digitbase, B.TPB);
             KCHECK();
         }
         {
             ProfScope ps(c, P_RADIX_SCATTER);
             if (ft)
-                k2_radix_scatter<true><<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(
+                k2_radix_scatter<true, DB, STG><<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(
                     kin, kout, cntArr, B.state, B.tilehist, B.digitbase, B.S, B.TPB, shift, tiles, nbarg(nb, 8),
                     B.T, B.present, c->r0bits);
             else
-                k2_radix_scatter<false><<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(
+                k2_radix_scatter<false, DB, STG><<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(
                     kin, kout, cntArr, B.state, B.tilehist, B.digitbase, B.S, B.TPB, shift, tiles, nbarg(nb, 8),
                     B.T, B.present, c->r0bits);
             KCHECK();
         }
         std::swap(kin, kout);
+    }
+}
+
+// sorts the 40 key bits [59:20]: 5 passes of 8 bits or 4 of 10 (c->radix_bits); the sorted words end
+// in `bbuf` when the pass count is odd, in `a` when it is even
+static int radix_passes(const bz2hip_ctx *c) { return 40 / (int)c->radix_bits; }
+static void radix_sort5(bz2hip_ctx *c, int nb, u32 maxcnt, const u32 *cntArr, u64 *a, u64 *bbuf,
+                        bool from_T = false) {
+    if (c->radix_bits == 10) {
+        if (c->radix_stage) radix_sort_db<10, true>(c, nb, maxcnt, cntArr, a, bbuf, 4, from_T);
+        else radix_sort_db<10, false>(c, nb, maxcnt, cntArr, a, bbuf, 4, from_T);
+    } else {
+        if (c->radix_stage) radix_sort_db<8, true>(c, nb, maxcnt, cntArr, a, bbuf, 5, from_T);
+        else radix_sort_db<8, false>(c, nb, maxcnt, cntArr, a, bbuf, 5, from_T);
     }
 }
 
@@ -1592,12 +1715,12 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
     k2_reset<<<cb, 256, 0, c->stream>>>(B.n, B.present, B.mS, B.mL, B.mSn, B.mLn, B.hcur, B.huse,
                                         B.state, B.par, B.rounds, B.leftg, B.periodic, B.ctl, nb, c->r0bits);
     KCHECK();
-    const int r0p = (int)c->r0bits / 8;
+    const int r0p = radix_passes(c); // r0bits = 40 key bits
     // The first pass reads the block bytes, so the keys are first written by its scatter.  The
     // sorted keys must end in keyB (the L-list is rebuilt into keyA): with an odd pass count the
     // passes go (T) -> keyB -> keyA -> ... -> keyB, so the "input" of pass 0 is nominally keyA.
-    if (r0p & 1) radix_sort5(c, nb, maxn, B.n, B.keyA, B.keyB, r0p, true);
-    else radix_sort5(c, nb, maxn, B.n, B.keyB, B.keyA, r0p, true);
+    if (r0p & 1) radix_sort5(c, nb, maxn, B.n, B.keyA, B.keyB, true);
+    else radix_sort5(c, nb, maxn, B.n, B.keyB, B.keyA, true);
     lrerank<MODE_ROUND0>(c, nb, maxn, B.n, ST_ACTIVE, B.keyB, B.keyA);
     bool first = true;
     int rnd = 0; // doubling rounds launched so far
@@ -1629,11 +1752,11 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
         const u32 maxS = hc[1], maxL = hc[2];
         if (c->debug >= 2)
             fprintf(stderr, "[bz2hip] round: maxS=%u maxL=%u sumS=%u sumL=%u\n", maxS, maxL, hc[7], hc[3]);
-        c->st_sorted_elems += (u64)hc[3] * 5;
+        c->st_sorted_elems += (u64)hc[3] * r0p;
         c->st_s_elems += hc[7];
         if (c->profile) {
-            c->prof_bytes[P_RADIX_SCATTER] += 5.0 * 16.0 * (double)hc[3];
-            c->prof_bytes[P_RADIX_HIST] += 5.0 * 8.0 * (double)hc[3];
+            c->prof_bytes[P_RADIX_SCATTER] += r0p * 16.0 * (double)hc[3];
+            c->prof_bytes[P_RADIX_HIST] += r0p * 8.0 * (double)hc[3];
             // keys: read E 8 + gather rank 4 + write E 8; ssort: read E 8 + write E 8 (LDS sort)
             c->prof_bytes[P_BWT_KEYS] += 20.0 * ((double)hc[3] + (double)hc[7]);
             c->prof_bytes[P_BWT_SSORT] += 16.0 * (double)hc[7];
@@ -1681,6 +1804,8 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
                 KCHECK();
             }
             radix_sort5(c, nb, maxL, B.mL, B.keyA, B.keyB);
+            // an even number of passes leaves the sorted list in keyA: the two buffers trade names
+            if (!(r0p & 1)) std::swap(B.keyA, B.keyB);
             lrerank<MODE_NORMAL>(c, nb, maxL, B.mL, ST_ACTIVE, B.keyB, B.keyA);
             if (fork) {
                 HIPCHK(hipEventRecord(c->ev_join, c->stream));
@@ -1699,7 +1824,14 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
         }
         rnd++;
     }
-    // the loop above ended on a device round trip: everything but the tie flush below has run
+    {
+        // every finished rotation's BWT byte, in one streaming pass (before the tie flush, which
+        // overwrites the slots of tied rotations with the same bytes, one per slot)
+        ProfScope ps(c, P_BWT_EMIT);
+        k2_emit_bwt<<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(B.n, B.rank, B.T, B.bwt, B.S, tiles, (u32)nb);
+        KCHECK();
+    }
+    // the loop above ended on a device round trip: only the emit pass and the tie flush remain
     c->st_bwt_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     if (anyfin) {
         // periodic blocks: flush the k-fold ties in list order
