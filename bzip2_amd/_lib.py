@@ -25,6 +25,7 @@ SYMBOLS = [
     "bz2hip_last_stats", "bz2hip_last_stats2", "bz2hip_decompress", "bz2hip_decompress_device",
     "bz2hip_compress_device_noalloc", "bz2hip_shard_scan", "bz2hip_shard_chain",
     "bz2hip_shard_compress", "bz2hip_stitch_device", "bz2hip_host_alloc", "bz2hip_host_free",
+    "bz2hip_tie_stats",
 ]
 
 
@@ -120,6 +121,8 @@ def load():
     L.bz2hip_shard_chain.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int, u32p, C.POINTER(C.c_uint64)]
     L.bz2hip_shard_compress.restype = C.c_int
     L.bz2hip_shard_compress.argtypes = [vp, vp, sz, C.POINTER(C.c_uint64), vp, C.c_uint32, u32p]
+    L.bz2hip_tie_stats.restype = C.c_int
+    L.bz2hip_tie_stats.argtypes = [vp, vp, vp, vp]
     L.bz2hip_host_alloc.restype = C.c_int
     L.bz2hip_host_alloc.argtypes = [C.POINTER(vp), sz]
     L.bz2hip_host_free.restype = None
@@ -448,6 +451,12 @@ class Context:
         self.L.bz2hip_profile_get(self.h, C.byref(cnt), names, ms, launches, ab)
         return {names[i].decode(): {"ms": ms[i], "launches": launches[i], "alg_bytes": ab[i]}
                 for i in range(cnt.value)}
+
+    def tie_stats(self):
+        """periodic blocks since the context was created: replays run, results reused, cached keys"""
+        v = [C.c_uint64(0) for _ in range(3)]
+        self.L.bz2hip_tie_stats(self.h, *[C.byref(x) for x in v])
+        return {"replays": v[0].value, "reused": v[1].value, "cached_keys": v[2].value}
 
     def last_stats(self):
         v = [C.c_uint64(0) for _ in range(4)]

@@ -288,6 +288,8 @@ extern "C" int bz2hip_create(bz2hip_ctx **out, const bz2hip_opts *opts) {
         HIPCHK(hipEventCreateWithFlags(&c->crc_done, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_tie, hipEventDisableTiming));
+        HIPCHK(hipStreamCreate(&c->stream_tie));
         // this device's copy of the static scratch (device `dev` is current)
         void *sp = nullptr;
         HIPCHK(hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch)));
@@ -297,6 +299,8 @@ extern "C" int bz2hip_create(bz2hip_ctx **out, const bz2hip_opts *opts) {
         if (c->crc_done) (void)hipEventDestroy(c->crc_done);
         if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
         if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+        if (c->ev_tie) (void)hipEventDestroy(c->ev_tie);
+        if (c->stream_tie) (void)hipStreamDestroy(c->stream_tie);
         (void)hipStreamDestroy(c->stream);
         (void)hipStreamDestroy(c->stream_other);
         delete c;
@@ -340,6 +344,8 @@ extern "C" void bz2hip_destroy(bz2hip_ctx *c) {
     if (c->crc_done) (void)hipEventDestroy(c->crc_done);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_tie) (void)hipEventDestroy(c->ev_tie);
+    if (c->stream_tie) { (void)hipStreamSynchronize(c->stream_tie); (void)hipStreamDestroy(c->stream_tie); }
     (void)hipStreamDestroy(c->stream);
     (void)hipStreamDestroy(c->stream_other);
     delete c;
@@ -1302,6 +1308,7 @@ extern "C" int bz2hip_bwt(bz2hip_ctx *c, const uint8_t *blocks, const uint32_t *
             HIPCHK(hipMemcpy(B.n, n + b0, nb * sizeof(u32), hipMemcpyHostToDevice));
             run_present(c, nb, maxn);
             run_bwt_n(c, nb, maxn);
+            run_tie_finish(c, nb);
             HIPCHK(hipStreamSynchronize(c->stream));
             if (maxn) HIPCHK(hipMemcpy2D(bwt + (size_t)b0 * stride, stride, B.bwt, B.S, maxn, nb, hipMemcpyDeviceToHost));
             HIPCHK(hipMemcpy(orig + b0, B.orig, nb * sizeof(u32), hipMemcpyDeviceToHost));
@@ -1522,6 +1529,16 @@ extern "C" int bz2hip_last_stats3(bz2hip_ctx *c, double *bwt_seconds, uint64_t *
     if (!c) return BZ2HIP_E_PARAM;
     if (bwt_seconds) *bwt_seconds = c->st_bwt_seconds;
     if (tie_traps) *tie_traps = c->st_tie_traps;
+    return BZ2HIP_OK;
+}
+
+extern "C" int bz2hip_tie_stats(bz2hip_ctx *c, uint64_t *replays, uint64_t *reused, uint64_t *cached_keys) {
+    if (!c) return BZ2HIP_E_PARAM;
+    u64 r = c->st_tie_replays, u = c->st_tie_cached, k = c->tie_cache.size();
+    for (bz2hip_ctx *p : c->peers) { r += p->st_tie_replays; u += p->st_tie_cached; k += p->tie_cache.size(); }
+    if (replays) *replays = r;
+    if (reused) *reused = u;
+    if (cached_keys) *cached_keys = k;
     return BZ2HIP_OK;
 }
 

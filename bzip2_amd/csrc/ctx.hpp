@@ -3,7 +3,9 @@
 #include "common.hpp"
 #include "../../include/bz2hip.h"
 
+#include <map>
 #include <string>
+#include <tuple>
 #include <vector>
 #include <stdexcept>
 #include <cstdio>
@@ -37,6 +39,22 @@ struct Carver {
     }
 };
 
+
+// Periodic blocks (block == w^k): what identifies one for the origin-pointer cache, and a batch's
+// pending decisions (k2_tie.hip).
+struct TieKey {
+    u32 level, n, k;
+    u64 h1, h2;
+    bool operator<(const TieKey &o) const {
+        return std::tie(level, n, k, h1, h2) < std::tie(o.level, o.n, o.k, o.h1, o.h2);
+    }
+};
+struct TieItem {
+    int block;   // block of the batch
+    int rep;     // block whose replay gives the value (== block: runs it itself), -1: from the cache
+    u32 orig;
+    TieKey key;
+};
 
 // Device workspace for one batch of up to NB blocks laid out at stride S elements.
 struct Batch {
@@ -93,6 +111,8 @@ struct Batch {
     u32 *pkagg = nullptr;     // [NB][S/PK_TILE] tile bit sums -> offsets
     size_t bytes = 0;
     std::vector<void *> allocs; // device allocations of this workspace
+    std::vector<TieItem> tie_items; // periodic blocks of the batch in flight (host side)
+    bool tie_running = false;
 };
 
 struct ProfRec {
@@ -139,6 +159,10 @@ struct bz2hip_ctx {
     u8 *scratch = nullptr;   // this device's address of the static scratch array (api.hip)
     hipEvent_t crc_done = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr; // S-sort || L-path inside a doubling round
+    hipStream_t stream_tie = nullptr;  // replays of the reference's sorter for periodic blocks
+    hipEvent_t ev_tie = nullptr;
+    std::map<TieKey, u32> tie_cache;   // origin pointers of periodic blocks seen so far
+    u64 st_tie_replays = 0, st_tie_cached = 0; // since the context was created
     size_t w_cap = 0;        // window capacity in input bytes
     u32 w_maxblocks = 0;
     u32 w_ETPB = 0;          // emit tiles per block slot
@@ -238,7 +262,8 @@ struct ProfScope {
 // stage drivers (each in its own .hip file)
 void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn);                       // k2_bwt.hip
 void run_present(bz2hip_ctx *c, int nb, u32 maxn);                     // k2_bwt.hip
-void run_tie(bz2hip_ctx *c, int nb);                                   // k2_tie.hip
+void run_tie_launch(bz2hip_ctx *c, int nb);                            // k2_tie.hip
+void run_tie_finish(bz2hip_ctx *c, int nb);                            // k2_tie.hip
 void run_mtf(bz2hip_ctx *c, int nb, u32 maxn);                         // k3_mtf.hip
 void run_huffman(bz2hip_ctx *c, int nb, u32 maxmtf);                   // k4_huffman.hip
 // writes blocks at absolute bit offsets into d_out (zeroed); first_bit = bit offset of block 0

@@ -53,7 +53,8 @@ enum { CLS_NONE = 0, CLS_SINGLE = 1, CLS_SMALL = 2, CLS_LKEEP = 3 };
 // ------------------------------------------------------------------ per-block control
 __global__ void k2_reset(const u32 *__restrict__ nArr, const u32 *__restrict__ present,
                          u32 *mS, u32 *mL, u32 *mSn, u32 *mLn, u32 *hcur, u32 *huse, u32 *state,
-                         u32 *par, u32 *rounds, u32 *leftg, u32 *periodic, u32 *ctl, u32 nb, u32 r0bits) {
+                         u32 *par, u32 *rounds, u32 *leftg, u32 *periodic, u32 *gcount, u32 *ctl, u32 nb,
+                         u32 r0bits) {
     u32 b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
     u32 uniq = 0;
@@ -64,23 +65,51 @@ __global__ void k2_reset(const u32 *__restrict__ nArr, const u32 *__restrict__ p
     mS[b] = 0; mL[b] = 0; mSn[b] = 0; mLn[b] = 0;
     hcur[b] = d0; huse[b] = d0;
     state[b] = nArr[b] > 0 ? ST_ACTIVE : ST_DONE;
-    par[b] = 0; rounds[b] = 0; leftg[b] = 0; periodic[b] = 1;
+    par[b] = 0; rounds[b] = 0; leftg[b] = 0; periodic[b] = 1; gcount[b] = 0;
     atomicAdd(&ctl[8], nArr[b]);
 }
 
-// after every round: move the "next" counters in, decide who continues
-__global__ void k2_ctl(const u32 *__restrict__ nArr, u32 *mS, u32 *mL, u32 *mSn, u32 *mLn,
-                       u32 *hcur, u32 *huse, u32 *state, u32 *par, u32 *rounds, u32 *ctl, u32 nb) {
-    u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+// after every round: move the "next" counters in, decide who continues.  One workgroup per block.
+// A block whose rotations are ALL still listed, in g groups of equal size k = n / g >= 2, may be a
+// perfect power w^k with |w| = g: if T has the cyclic period g, rotations i and i + g are the same
+// string, every group holds at least one such class, and g groups over n rotations leave room for
+// exactly one class each -- the groups are the k-fold ties and can never split.  The block is then
+// finished now (its ties are flushed in list order) instead of doubling on to h >= n: "ab...",
+// zeros and the like take one or two rounds instead of log2(n).
+__global__ __launch_bounds__(256) void k2_ctl(const u32 *__restrict__ nArr, u32 *mS, u32 *mL, u32 *mSn, u32 *mLn,
+                                              u32 *hcur, u32 *huse, u32 *state, u32 *par, u32 *rounds,
+                                              u32 *gcount, const u8 *__restrict__ T, u32 S, u32 *ctl, u32 nb) {
+    const u32 b = blockIdx.x;
     if (b >= nb) return;
     if (state[b] != ST_ACTIVE) return;
-    u32 s = mSn[b], l = mLn[b];
+    __shared__ u32 sh[6];
+    __shared__ u32 s_bad;
+    if (threadIdx.x == 0) {
+        sh[0] = mSn[b]; sh[1] = mLn[b]; sh[2] = nArr[b]; sh[3] = hcur[b]; sh[4] = gcount[b];
+        s_bad = 0;
+    }
+    __syncthreads();
+    const u32 s = sh[0], l = sh[1], n = sh[2], h = sh[3], g = sh[4];
+    bool fin = (s + l != 0) && h >= n;
+    if (!fin && s + l == n && g >= 1 && n % g == 0 && n / g >= 2) {
+        const u8 *t = T + (size_t)b * S;
+        u32 bad = 0;
+        for (u32 i = threadIdx.x; i < n && !bad; i += 256) {
+            u32 j = i + g;
+            if (j >= n) j -= n;
+            bad |= (t[i] != t[j]);
+        }
+        if (bad) atomicOr(&s_bad, 1u);
+        __syncthreads();
+        fin = s_bad == 0;
+    }
+    if (threadIdx.x != 0) return;
     mS[b] = s; mL[b] = l; mSn[b] = 0; mLn[b] = 0;
+    gcount[b] = 0;
     par[b] ^= 1u; // survivors were written to the other S buffer
-    u32 n = nArr[b], h = hcur[b];
     if (s + l == 0) {
         state[b] = ST_DONE;
-    } else if (h >= n) {
+    } else if (fin) {
         state[b] = ST_FIN;
         atomicOr(&ctl[4], 1u);
         atomicMax(&ctl[5], s);
@@ -533,7 +562,7 @@ __device__ __forceinline__ void tile_emit(const u64 *buf, int cnt, const int (&c
                                           u32 *__restrict__ rank, const u8 *__restrict__ T,
                                           u8 *__restrict__ bwt, u32 n, u64 *__restrict__ sOut,
                                           u32 *mSn_b, u64 *__restrict__ lOut, u32 lBase,
-                                          int *sm /* 12 ints */, u32 rlo = 0, u32 rhi = ~0u,
+                                          int *sm /* 16 ints */, u32 *gcount_b, u32 rlo = 0, u32 rhi = ~0u,
                                           bool mainSweep = true) {
     const int w = wave_id(), lane = lane_id();
     if (!mainSweep) {
@@ -548,25 +577,31 @@ __device__ __forceinline__ void tile_emit(const u64 *buf, int cnt, const int (&c
         }
         return;
     }
-    // counts of SMALL and LKEEP per wave
-    u32 cs = 0, cl = 0;
+    // counts of SMALL and LKEEP per wave, and of the groups that stay listed (a survivor whose
+    // slot is its group's rank is that group's head)
+    u32 cs = 0, cl = 0, ch = 0;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         cs += (cls[k] == CLS_SMALL);
         cl += (cls[k] == CLS_LKEEP);
+        ch += ((cls[k] == CLS_SMALL || cls[k] == CLS_LKEEP) && spos[k] == ngrp[k]);
     }
     if (MODE != MODE_FINAL) {
         cs = wave_reduce_add(cs);
         cl = wave_reduce_add(cl);
+        ch = wave_reduce_add(ch);
         __syncthreads();
         if (lane == 0) {
             sm[w] = (int)cs;
             sm[4 + w] = (int)cl;
+            sm[12 + w] = (int)ch;
         }
         __syncthreads();
         if (threadIdx.x == 0) {
             u32 tot = (u32)(sm[0] + sm[1] + sm[2] + sm[3]);
             sm[8] = tot ? (int)atomicAdd(mSn_b, tot) : 0;
+            u32 th = (u32)(sm[12] + sm[13] + sm[14] + sm[15]);
+            if (th) atomicAdd(gcount_b, th);
         }
         __syncthreads();
     }
@@ -732,8 +767,8 @@ __global__ __launch_bounds__(RT_THREADS) void k2_lrerank_p3(
     const u32 *__restrict__ par, const u32 *__restrict__ cntArr,
     const u32 *__restrict__ state, u32 want, const u32 *__restrict__ tileagg,
     u32 *__restrict__ rank, const u8 *__restrict__ T, u8 *__restrict__ bwt,
-    const u32 *__restrict__ nArr, u32 *__restrict__ mSn, u32 S, u32 TPB, u32 gtiles, u32 gnb,
-    u32 nsw) {
+    const u32 *__restrict__ nArr, u32 *__restrict__ mSn, u32 *__restrict__ gcount, u32 S, u32 TPB,
+    u32 gtiles, u32 gnb, u32 nsw) {
     // round 0 writes the rank of every position, in sorted order: a block's rank array does not
     // stay in its XCD's L2 next to the streaming lists, so the pass is swept nsw times, each
     // sweep writing only the ranks that fall in one 1/nsw window of positions
@@ -777,7 +812,7 @@ __global__ __launch_bounds__(RT_THREADS) void k2_lrerank_p3(
     u64 *sOut = (par[b] ? slA : slB) + (size_t)b * S;
     const u32 nblk = nArr[b], win = (nblk + nsw - 1) / nsw;
     tile_emit<MODE>(buf, cnt, cls, ngrp, spos, rank + (size_t)b * S, T + (size_t)b * S,
-                    bwt + (size_t)b * S, nblk, sOut, mSn + b, lOutAll + (size_t)b * S, lBase, sm,
+                    bwt + (size_t)b * S, nblk, sOut, mSn + b, lOutAll + (size_t)b * S, lBase, sm, gcount + b,
                     nsw > 1 ? sweep * win : 0u, nsw > 1 ? (sweep + 1) * win : ~0u, sweep == 0);
 }
 
@@ -1279,6 +1314,7 @@ __global__ __launch_bounds__(RT_THREADS, 3) void k2_ssort(const u64 *slA, const 
                                                        const u32 *__restrict__ huse,
                                                        u32 *__restrict__ pvote,
                                                        const u32 *__restrict__ runs,
+                                                       u32 *__restrict__ gcount,
                                                        u32 S, u32 gtiles, u32 gnb) {
     XCD_MAP(gtiles, gnb)
     const u32 b = bz_b;
@@ -1442,7 +1478,7 @@ __global__ __launch_bounds__(RT_THREADS, 3) void k2_ssort(const u64 *slA, const 
         PH_MARK(6);
         __syncthreads();
         // counts
-        u32 cN = 0, cU = 0;
+        u32 cN = 0, cU = 0, cH = 0; // cH: groups that pass through untouched (they stay listed)
         u32 st2 = 0; // per lane, 2 bits per row: bit 0 = goes to the sort, bit 1 = passes through
 #pragma unroll
         for (int k = 0; k < 16; k++) {
@@ -1461,16 +1497,24 @@ __global__ __launch_bounds__(RT_THREADS, 3) void k2_ssort(const u64 *slA, const 
             const bool uni = in_span && !nonuni;
             st2 |= ((nonuni ? 1u : 0u) | (uni ? 2u : 0u)) << (2 * k);
             cN += __popcll(__ballot(nonuni));
-            cU += __popcll(__ballot(uni));
+            const u64 um = __ballot(uni);
+            cU += __popcll(um);
+            cH += __popcll(um & hm[k]);
         }
         if (lane == 0) {
             sm[4 + w] = (int)cN;
             sm[8 + w] = (int)cU;
+            sm[12 + w] = (int)cH;
         }
         __syncthreads();
         PH_MARK(7);
         const int totN = sm[4] + sm[5] + sm[6] + sm[7];
         const int totU = sm[8] + sm[9] + sm[10] + sm[11];
+        if (threadIdx.x == 0) {
+            const u32 totH = (u32)(sm[12] + sm[13] + sm[14] + sm[15]);
+            if (totH) atomicAdd(gcount + b, totH);
+        }
+        __syncthreads();
         if (threadIdx.x == 0) sm[12] = totU ? (int)atomicAdd(mSn + b, (u32)totU) : 0;
         __syncthreads();
         u32 nRun = 0, uRun = (u32)sm[12];
@@ -1534,7 +1578,7 @@ __global__ __launch_bounds__(RT_THREADS, 3) void k2_ssort(const u64 *slA, const 
     if (MODE == MODE_FINAL && threadIdx.x == 0) atomicAdd(&leftg[b], (u32)nheads);
     PH_MARK(3);
     tile_emit<MODE, true>(buf, cnt, cls, ngrp, spos, rank + (size_t)b * S, T + (size_t)b * S,
-                    bwt + (size_t)b * S, nArr[b], out, mSn + b, (u64 *)nullptr, 0, sm);
+                    bwt + (size_t)b * S, nArr[b], out, mSn + b, (u64 *)nullptr, 0, sm, gcount + b);
     PH_MARK(4);
 }
 
@@ -1700,7 +1744,7 @@ static void lrerank(bz2hip_ctx *c, int nb, u32 maxcnt, const u32 *cntArr, u32 wa
     const u32 nsw = (MODE == MODE_ROUND0) ? c->r0_sweeps : 1u;
     k2_lrerank_p3<MODE><<<xcd_grid(tiles * nsw, nb), RT_THREADS, 0, c->stream>>>(
         sorted, lout, B.slA, B.slB, B.par, cntArr, B.state, want, B.tileagg, B.rank, B.T, B.bwt, B.n,
-        B.mSn, B.S, B.TPB, tiles, nbarg(nb, 4), nsw);
+        B.mSn, B.nheads, B.S, B.TPB, tiles, nbarg(nb, 4), nsw);
     KCHECK();
 }
 
@@ -1713,7 +1757,7 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
     const int cb = (nb + 255) / 256;
     HIPCHK(hipMemsetAsync(B.ctl, 0, 16 * sizeof(u32), c->stream));
     k2_reset<<<cb, 256, 0, c->stream>>>(B.n, B.present, B.mS, B.mL, B.mSn, B.mLn, B.hcur, B.huse,
-                                        B.state, B.par, B.rounds, B.leftg, B.periodic, B.ctl, nb, c->r0bits);
+                                        B.state, B.par, B.rounds, B.leftg, B.periodic, B.nheads, B.ctl, nb, c->r0bits);
     KCHECK();
     const int r0p = radix_passes(c); // r0bits = 40 key bits
     // The first pass reads the block bytes, so the keys are first written by its scatter.  The
@@ -1730,8 +1774,8 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
     for (;;) {
         HIPCHK(hipMemsetAsync(B.ctl, 0, 4 * sizeof(u32), c->stream));
         HIPCHK(hipMemsetAsync(B.ctl + 7, 0, sizeof(u32), c->stream));
-        k2_ctl<<<cb, 256, 0, c->stream>>>(B.n, B.mS, B.mL, B.mSn, B.mLn, B.hcur, B.huse, B.state, B.par,
-                                          B.rounds, B.ctl, nb);
+        k2_ctl<<<nb, 256, 0, c->stream>>>(B.n, B.mS, B.mL, B.mSn, B.mLn, B.hcur, B.huse, B.state, B.par,
+                                          B.rounds, B.nheads, B.T, B.S, B.ctl, nb);
         KCHECK();
         u32 hc[9];
         HIPCHK(hipMemcpyAsync(hc, B.ctl, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
@@ -1781,7 +1825,7 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
             k2_ssort<MODE_NORMAL><<<xcd_grid((maxS + SC - 1) / SC, nb), RT_THREADS, 0, c->stream>>>(
                 B.slA, B.slB, B.slA, B.slB, B.par, B.mS, B.state, ST_ACTIVE, B.rank, B.T, B.bwt, B.n,
                 B.mSn, B.leftg, B.huse, rnd == 0 ? B.pvote : (u32 *)nullptr,
-                rnd == 0 ? (const u32 *)nullptr : B.runs, B.S, (maxS + SC - 1) / SC, nbarg(nb, 2));
+                rnd == 0 ? (const u32 *)nullptr : B.runs, B.nheads, B.S, (maxS + SC - 1) / SC, nbarg(nb, 2));
             KCHECK();
             KCHECK();
         }
@@ -1839,7 +1883,7 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
             ProfScope ps(c, P_BWT_SSORT);
             k2_ssort<MODE_FINAL><<<xcd_grid((finS + SC - 1) / SC, nb), RT_THREADS, 0, c->stream>>>(
                 B.slA, B.slB, B.slA, B.slB, B.par, B.mS, B.state, ST_FIN, B.rank, B.T, B.bwt, B.n,
-                B.mSn, B.leftg, B.huse, (u32 *)nullptr, (const u32 *)nullptr, B.S, (finS + SC - 1) / SC,
+                B.mSn, B.leftg, B.huse, (u32 *)nullptr, (const u32 *)nullptr, B.nheads, B.S, (finS + SC - 1) / SC,
                 nbarg(nb, 2));
             KCHECK();
         }
@@ -1852,5 +1896,7 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
         KCHECK();
     }
     // periodic blocks: the reference's origin pointer depends on its sorter's tie order (k2_tie.hip)
-    if (anyfin && c->opts.tie_rule == BZ2HIP_TIE_REFERENCE) run_tie(c, nb);
+    B.tie_items.clear();
+    B.tie_running = false;
+    if (anyfin && c->opts.tie_rule == BZ2HIP_TIE_REFERENCE) run_tie_launch(c, nb);
 }

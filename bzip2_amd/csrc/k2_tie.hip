@@ -1175,20 +1175,67 @@ static __device__ int constructBWT(dss_t *D, int *bucketA, int *bucketB) {
 #undef SA
 #undef T
 
-// One workgroup (one wave) per block.  Scratch comes from the sort buffers, which are dead once
-// k2_finish has run: keyA[b] holds SA (blockSize + 1 ints) and the T copy (n + 1 bytes), keyB[b] the
-// two bucket tables.
+// ------------------------------------------------------------------ which blocks need the replay
+// The replay's result is a pure function of (period word w, k, declared block size): identical
+// periodic blocks -- every full block of "ab...", of zeros, of any repeated unit -- need it once.
+// Two independent 64-bit sums over the period word (position-mixed, order-independent so that a
+// wave can add them in any order) identify w; the context caches origin pointers by
+// (level, n, k, hash) and a batch runs one replay per distinct key it has not seen.
+__device__ __forceinline__ u64 mix64(u64 x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__global__ __launch_bounds__(256) void k2_tie_hash(const u32 *__restrict__ nArr,
+                                                   const u32 *__restrict__ periodic,
+                                                   const u8 *__restrict__ Tsrc, u64 *__restrict__ hash, u32 S) {
+    const u32 b = blockIdx.x;
+    const u32 n = nArr[b], k = periodic[b];
+    if (k <= 1 || k >= n) return;
+    const u32 p = n / k;
+    const u8 *t = Tsrc + (size_t)b * S;
+    u64 h1 = 0, h2 = 0;
+    for (u32 i = threadIdx.x; i < p; i += 256) {
+        const u64 v = (u64)t[i] + 1u;
+        h1 += mix64(((u64)i << 9) | v);
+        h2 += mix64((((u64)i << 9) | v) ^ 0xA5A5A5A5A5A5A5A5ull) * (2 * (u64)i + 1);
+    }
+    __shared__ u64 s1[256], s2[256];
+    s1[threadIdx.x] = h1;
+    s2[threadIdx.x] = h2;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if ((int)threadIdx.x < d) {
+            s1[threadIdx.x] += s1[threadIdx.x + d];
+            s2[threadIdx.x] += s2[threadIdx.x + d];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        hash[2 * b] = s1[0];
+        hash[2 * b + 1] = s2[0];
+    }
+}
+
+// One workgroup (one wave) per block that is marked in `todo`.  Scratch comes from the sort buffers,
+// which are dead once k2_finish has run: keyA[b] holds SA (blockSize + 1 ints) and the T copy (n + 1
+// bytes), keyB[b] the two bucket tables.  ctlw[0] = traps, ctlw[1] = BWT bytes that disagree with
+// the parallel sort's, ctlw[2] = origin pointers outside the class of rotation 0 (both must be 0).
 __global__ __launch_bounds__(64) void k2_tie_divsufsort(const u32 *__restrict__ nArr,
                                                         const u32 *__restrict__ periodic,
+                                                        const u32 *__restrict__ todo,
                                                         const u8 *__restrict__ Tsrc,
-                                                        const u8 *__restrict__ bwt, u64 *keyA,
+                                                        const u8 *__restrict__ bwt,
+                                                        const u32 *__restrict__ rank, u64 *keyA,
                                                         u64 *keyB, u32 *__restrict__ orig,
-                                                        u32 *__restrict__ mismatch, u32 *__restrict__ traps, u32 S,
+                                                        u32 *__restrict__ ctlw, u32 S,
                                                         u32 blockSize) {
     const u32 b = blockIdx.x;
     const u32 n = nArr[b];
     const u32 k = periodic[b];
-    if (k <= 1 || k >= n) return; // aperiodic, or all-equal (orig 0, D:3168-3174,3505)
+    if (!todo[b] || k <= 1 || k >= n) return; // aperiodic, all-equal (orig 0, D:3168-3174,3505), or known
     int *sa = (int *)(keyA + (size_t)b * S);
     u8 *t = (u8 *)(sa + S + 2);
     int *bucketB = (int *)(keyB + (size_t)b * S);
@@ -1210,33 +1257,125 @@ __global__ __launch_bounds__(64) void k2_tie_divsufsort(const u32 *__restrict__ 
         D.trap = 0;
         int m = sortTypeBstar(&D, bucketA, bucketB); // D:3501
         s_orig = (0 < m) ? constructBWT(&D, bucketA, bucketB) : 0; // D:3502-3505
-        if (D.trap) atomicAdd(traps, 1u);
+        if (D.trap) atomicAdd(&ctlw[0], 1u);
     }
     __syncthreads();
-    // the sorter's own BWT bytes must agree with the parallel sort's (debug counter)
+    // the sorter's own BWT bytes must agree with the parallel sort's
     u32 bad = 0;
     const u8 *mine = bwt + (size_t)b * S;
     for (u32 i = threadIdx.x; i < n; i += 64) bad += ((u32)(sa[i] & 0xff) != (u32)mine[i]);
     bad = wave_reduce_add(bad);
     if (threadIdx.x == 0) {
         orig[b] = (u32)s_orig;
-        if (bad) atomicAdd(mismatch, bad);
+        if (bad) atomicAdd(&ctlw[1], bad);
+        // whatever the tie order, the pointer must name one of the k rotations equal to rotation 0:
+        // they occupy sorted positions [rank(0), rank(0) + k)
+        const u32 r0 = rank[(size_t)b * S];
+        if ((u32)s_orig < r0 || (u32)s_orig >= r0 + k) atomicAdd(&ctlw[2], 1u);
     }
 }
 
 } // namespace
 
-void run_tie(bz2hip_ctx *c, int nb) {
+// Periodic blocks of the batch: hash their period words, look the keys up in the context's cache,
+// start one replay per distinct unknown key on the tie stream (it overlaps MTF / Huffman of the
+// batch: only the 24 origin-pointer bits of the block header depend on it,
+// S/BZip2BlockCompressor.swift:277).  run_tie_finish makes B.orig final.
+void run_tie_launch(bz2hip_ctx *c, int nb) {
     Batch &B = c->batch;
-    ProfScope ps(c, P_BWT_TIE);
-    k2_tie_divsufsort<<<nb, 64, 0, c->stream>>>(B.n, B.periodic, B.T, B.bwt, B.keyA, B.keyB, B.orig,
-                                                B.ctl + 15, B.ctl + 14, B.S, (u32)B.level * 100000u);
+    B.tie_items.clear();
+    B.tie_running = false;
+    u64 *d_hash = (u64 *)B.pvote;                 // votes are dead after the first doubling round
+    u32 *d_todo = B.pvote + 4 * (size_t)B.NB;     // [NB] behind the hashes ([NB][2] u64)
+    k2_tie_hash<<<nb, 256, 0, c->stream>>>(B.n, B.periodic, B.T, d_hash, B.S);
     KCHECK();
-    u32 h[2];
-    HIPCHK(hipMemcpyAsync(h, B.ctl + 14, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    std::vector<u32> hn(nb), hk(nb);
+    std::vector<u64> hh((size_t)nb * 2);
+    HIPCHK(hipMemcpyAsync(hn.data(), B.n, nb * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(hk.data(), B.periodic, nb * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(hh.data(), d_hash, (size_t)nb * 2 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (h[1])
-        throw HipError(BZ2HIP_E_HIP, "internal: periodic-block sorter and parallel BWT disagree on " +
-                                         std::to_string(h[1]) + " bytes");
-    c->st_tie_traps += h[0];
+    std::vector<u32> todo(nb, 0);
+    std::map<TieKey, int> first_in_batch; // key -> block that runs the replay
+    bool any = false;
+    for (int b = 0; b < nb; b++) {
+        if (hk[b] <= 1 || hk[b] >= hn[b]) continue;
+        TieItem it;
+        it.block = b;
+        it.key = TieKey{(u32)B.level, hn[b], hk[b], hh[2 * (size_t)b], hh[2 * (size_t)b + 1]};
+        auto hit = c->tie_cache.find(it.key);
+        if (hit != c->tie_cache.end()) {
+            it.rep = -1;
+            it.orig = hit->second;
+            c->st_tie_cached++;
+        } else {
+            auto f = first_in_batch.find(it.key);
+            if (f == first_in_batch.end()) {
+                first_in_batch[it.key] = b;
+                it.rep = b;
+                todo[b] = 1;
+                any = true;
+                c->st_tie_replays++;
+            } else {
+                it.rep = f->second;
+                c->st_tie_cached++;
+            }
+            it.orig = 0;
+        }
+        B.tie_items.push_back(it);
+    }
+    if (!any) return;
+    HIPCHK(hipMemcpyAsync(d_todo, todo.data(), nb * sizeof(u32), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(B.ctl + 13, 0, 3 * sizeof(u32), c->stream));
+    HIPCHK(hipEventRecord(c->ev_tie, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->stream_tie, c->ev_tie, 0));
+    {
+        hipStream_t keep = c->stream;
+        c->stream = c->stream_tie; // the profiling events of this scope belong to the tie stream
+        {
+            ProfScope ps(c, P_BWT_TIE);
+            k2_tie_divsufsort<<<nb, 64, 0, c->stream_tie>>>(B.n, B.periodic, d_todo, B.T, B.bwt, B.rank, B.keyA,
+                                                            B.keyB, B.orig, B.ctl + 13, B.S,
+                                                            (u32)B.level * 100000u);
+        }
+        c->stream = keep;
+        KCHECK();
+    }
+    B.tie_running = true;
+}
+
+// Waits for the batch's replays, checks them, remembers their results and writes the final origin
+// pointers of all periodic blocks of the batch into B.orig (on the main stream).
+void run_tie_finish(bz2hip_ctx *c, int nb) {
+    Batch &B = c->batch;
+    if (B.tie_items.empty()) return;
+    std::vector<u32> ho(nb, 0);
+    if (B.tie_running) {
+        HIPCHK(hipStreamSynchronize(c->stream_tie));
+        u32 h[3];
+        HIPCHK(hipMemcpyAsync(h, B.ctl + 13, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(ho.data(), B.orig, nb * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        B.tie_running = false;
+        if (h[1])
+            throw HipError(BZ2HIP_E_HIP, "internal: periodic-block sorter and parallel BWT disagree on " +
+                                             std::to_string(h[1]) + " bytes");
+        if (h[2])
+            throw HipError(BZ2HIP_E_HIP, "internal: origin pointer of a periodic block outside the class of rotation 0");
+        c->st_tie_traps += h[0];
+    }
+    if (c->tie_cache.size() > 8192) c->tie_cache.clear();
+    for (TieItem &it : B.tie_items)
+        if (it.rep == it.block) {
+            it.orig = ho[it.block];
+            c->tie_cache[it.key] = it.orig;
+        }
+    for (TieItem &it : B.tie_items)
+        if (it.rep >= 0 && it.rep != it.block) it.orig = ho[it.rep];
+    // patch: the items are few, one small copy each
+    for (const TieItem &it : B.tie_items)
+        if (it.rep != it.block)
+            HIPCHK(hipMemcpyAsync(B.orig + it.block, &it.orig, sizeof(u32), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream)); // the sources are host temporaries
+    B.tie_items.clear();
 }

@@ -738,6 +738,7 @@ void run_pack(bz2hip_ctx *c, int nb, u32 maxmtf, u8 *d_out, u64 first_bit, bool 
               size_t bits_stride, size_t out_cap_bytes, std::vector<u64> *h_nbits) {
     Batch &B = c->batch;
     if (nb == 0) return;
+    run_tie_finish(c, nb); // the block headers carry the origin pointers: they must be final now
     const u32 PKT = (B.S + 64 + PK_TILE - 1) / PK_TILE;
     {
         ProfScope ps(c, P_HUF_HEADER);

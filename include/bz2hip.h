@@ -251,6 +251,11 @@ int bz2hip_last_stats2(bz2hip_ctx *ctx, uint64_t *n_times_rounds, uint64_t *sort
  * which the reference's sorter would have indexed past its work array */
 int bz2hip_last_stats3(bz2hip_ctx *ctx, double *bwt_seconds, uint64_t *tie_traps);
 
+/* Periodic blocks since the context was created: replays of the reference's sorter actually run,
+ * blocks that reused a result (same period word, k and declared block size: from the context's
+ * cache or from a twin in the same batch), keys in the cache. */
+int bz2hip_tie_stats(bz2hip_ctx *ctx, uint64_t *replays, uint64_t *reused, uint64_t *cached_keys);
+
 #ifdef __cplusplus
 }
 #endif
