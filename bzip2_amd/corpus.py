@@ -221,6 +221,53 @@ def square_block(level=9, seed=7):
     return np.concatenate((w, w, rng.integers(0, 256, 5000, dtype=np.uint8)))
 
 
+ADVERSARIAL_FAMILIES = ("zeros", "ff", "fb", "ab", "abc", "period255", "period256", "period257", "runlens",
+                        "fibonacci", "thue_morse", "sawtooth", "sparse2", "square", "debruijn")
+
+
+def adversarial_family(name, n, seed=99):
+    """One adversarial input of n bytes."""
+    import zlib
+    rng = np.random.default_rng(seed + (zlib.crc32(name.encode()) & 0xffff))
+    if name == "zeros":
+        return np.zeros(n, dtype=np.uint8)
+    if name == "ff":
+        return np.full(n, 255, dtype=np.uint8)
+    if name == "fb":
+        return np.full(n, 0xFB, dtype=np.uint8)
+    if name == "ab":
+        return np.tile(np.frombuffer(b"ab", dtype=np.uint8), n // 2)
+    if name == "abc":
+        return np.tile(np.frombuffer(b"abc", dtype=np.uint8), n // 3)
+    if name.startswith("period"):
+        p = int(name[6:])
+        return np.tile(rng.integers(0, 256, p, dtype=np.uint8), n // p + 1)[:n].copy()
+    if name == "runlens":
+        lens = np.array([3, 4, 5, 254, 255, 256, 259, 510])
+        k = n // int(lens.mean()) + 8
+        rl = lens[np.arange(k) % 8]
+        vals = np.where(np.arange(k) & 1, ord("y"), ord("x")).astype(np.uint8)
+        return np.repeat(vals, rl)[:n].copy()
+    if name == "fibonacci":
+        return np.frombuffer(_fib_word(n), dtype=np.uint8).copy()
+    if name == "thue_morse":
+        return _thue_morse(n)
+    if name == "sawtooth":
+        reps = n // 45000 + 2  # one period of the saw (k = 1..300) is 45 450 bytes
+        kk = np.arange(1, 301)
+        unit = np.repeat(np.tile(np.array([ord("a"), ord("b")], dtype=np.uint8), 300),
+                         np.stack((kk, np.ones(300, dtype=np.int64)), axis=1).reshape(-1))
+        return np.tile(unit, reps)[:n].copy()
+    if name == "sparse2":
+        return (rng.random(n) < 0.01).astype(np.uint8) + ord("0")
+    if name == "square":
+        half = rng.integers(0, 256, n // 2, dtype=np.uint8)
+        return np.concatenate((half, half))
+    if name == "debruijn":
+        return (np.resize(_de_bruijn_bits(20), n) + ord("0")).astype(np.uint8)
+    raise ValueError(name)
+
+
 def adversarial(n=250000, seed=99):
     """Adversarial inputs at a size the CPU oracle handles in seconds."""
     rng = np.random.default_rng(seed)

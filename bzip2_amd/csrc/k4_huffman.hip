@@ -30,6 +30,9 @@ __global__ void k4_seed(const u32 *__restrict__ mtflen, const u32 *__restrict__ 
             int low_start = low_end + 1;
             int actual = 0;
             while (actual < target && low_end < alpha - 1) actual += (int)f[++low_end];
+            // D23: Java-original order (subtract the dropped symbol's frequency, then step back); the
+            // Swift text :164-167 steps back first and subtracts the new end's frequency.  The contract
+            // follows the Java original.
             if (low_end > low_start && i != 0 && i != tables - 1 && ((tables - i) & 1) == 0)
                 actual -= (int)f[low_end--];
             lo[i] = low_start;

@@ -451,6 +451,11 @@ int orc_huffman_optimise(const uint16_t *mtf, int mtf_len, int alpha, const int3
         int low_start = low_end + 1;
         int actual = 0;
         while (actual < target && low_end < alpha - 1) actual += freq[++low_end];
+        /* D23: the Java original reads `actual -= freq[lowCostEnd--]` (subtract the dropped symbol, then
+         * step back).  The Swift text (S/BZip2HuffmanStageEncoder.swift:164-167) steps back first and
+         * subtracts the NEW end's frequency, and keeps no Java comment there; that changes
+         * remainingLength, the later seeds and the bytes.  The contract is the Java original
+         * (DESIGN.md section 2); frozen by tests/golden `d23_backoff`. */
         if (low_end > low_start && i != 0 && i != tables - 1 && ((tables - i) & 1) == 0)
             actual -= freq[low_end--];
         for (int j = 0; j < alpha; j++)

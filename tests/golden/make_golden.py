@@ -42,6 +42,9 @@ def small_inputs():
         "text600": corpus.text(600, 5).tobytes(),
         "lowent": rng.integers(0, 2, 700, dtype=np.uint8).tobytes(),
         "hello": b"Hello, hello, hello world! " * 12,
+        # D23: 4 tables, the seed back-off branch is taken and the Java-original / Swift-text readings
+        # of it give different tables (tests/test_oracle.py::test_seed_backoff_follows_the_java_original_d23)
+        "d23_backoff": corpus.text(700, 5).tobytes(),
     }
     return v
 

@@ -139,14 +139,27 @@ def test_golden_large(ctx, idx):
         assert hashlib.sha256(out).hexdigest() == exp["sha256"]
 
 
-def test_adversarial(ctx, orc):
-    adv = corpus.adversarial(250000)
-    for k, d in adv.items():
-        for level in (1, 9):
-            want, _ = orc.compress(d, level)
-            got = ctx.compress(d, level)
-            assert got == want, (k, level)
-            assert bz2.decompress(got) == d.tobytes()
+# every family at >= 4 level-9 blocks (run-heavy families need far more input
+# for that: a -9 block of zeros swallows 46 MB), at -9 and at -1
+_ADV_SIZES = {"zeros": 190_000_000, "ff": 190_000_000, "fb": 190_000_000, "ab": 3_700_000, "abc": 3_700_000,
+              "period255": 3_700_000, "period256": 3_700_000, "period257": 3_700_000, "runlens": 140_000_000,
+              "fibonacci": 3_700_000, "thue_morse": 3_700_000, "sawtooth": 110_000_000, "sparse2": 70_000_000,
+              "square": 3_700_000, "debruijn": 3_700_000}
+
+
+@pytest.mark.parametrize("family", sorted(_ADV_SIZES))
+def test_adversarial(ctx, orc, family):
+    d = corpus.adversarial_family(family, _ADV_SIZES[family])
+    for level in (9, 1):
+        want, nb = orc.compress(d, level, threads=8)
+        assert nb >= 4, (family, level, nb)
+        got = ctx.compress(d, level)
+        st = ctx.last_stats()
+        info = (family, level, f"blocks={st['blocks']}", f"rounds/blk={st['rounds_sum'] / max(st['blocks'], 1):.1f}",
+                f"periodic_blocks={st['periodic_blocks']}", f"tie={ctx.tie_stats()}")
+        assert st["blocks"] == nb, info
+        assert got == want, info
+    assert bz2.decompress(got) == d.tobytes()
 
 
 def _periodic_inputs():

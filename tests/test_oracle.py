@@ -249,3 +249,57 @@ def test_mt_equals_st(orc):
     a, na = orc.compress(d, 2, threads=1)
     b, nb = orc.compress(d, 2, threads=4)
     assert a == b and na == nb
+
+
+def _seeds(freq, alpha, mtf_len, tables, java_order):
+    """generateHuffmanOptimisationSeeds (S/BZip2HuffmanStageEncoder.swift:144-181) in both readings of
+    the back-off statement: the Java original `actual -= freq[lowCostEnd--]` (java_order) and the
+    Swift text's `lowCostEnd -= 1; actual -= freq[lowCostEnd]` (:164-167)."""
+    lengths = np.zeros((tables, alpha), dtype=np.int64)
+    remaining, low_end = mtf_len, -1
+    took_branch = False
+    for i in range(tables):
+        target = remaining // (tables - i)
+        low_start = low_end + 1
+        actual = 0
+        while actual < target and low_end < alpha - 1:
+            low_end += 1
+            actual += int(freq[low_end])
+        if low_end > low_start and i != 0 and i != tables - 1 and ((tables - i) & 1) == 0:
+            took_branch = True
+            if java_order:
+                actual -= int(freq[low_end])
+                low_end -= 1
+            else:
+                low_end -= 1
+                actual -= int(freq[low_end])
+        for j in range(alpha):
+            if j < low_start or j > low_end:
+                lengths[i, j] = 15
+        remaining -= actual
+    return lengths, took_branch
+
+
+def test_seed_backoff_follows_the_java_original_d23(orc):
+    """D23: where the Swift text and the Java original it ports disagree, the
+    contract is the Java original.  The first selection pass is re-derived from
+    both readings of the seed back-off; the oracle must equal the Java-order one, on an input where
+    the two readings give different tables (frozen in tests/golden as `d23_backoff`)."""
+    d = bytes.fromhex(json.load(open(os.path.join(HERE, "golden", "golden.json")))["small"]["d23_backoff"]["input_hex"])
+    used, blk, pres, crc = orc.rle1_block(d, 900000)
+    bw, orig, per = orc.bwt(blk)
+    mtf, alpha, freq = orc.mtf_rle2(bw, pres)
+    nt, lens, sel, iters = orc.huffman_optimise(mtf, alpha, freq, want_iters=True)
+    assert nt >= 4  # the back-off needs a middle table
+    got = {}
+    for java_order in (True, False):
+        seed, took = _seeds(freq, alpha, mtf.size, nt, java_order)
+        assert took
+        tf = np.zeros((nt, alpha), dtype=np.int64)
+        for g in range(0, mtf.size, 50):
+            grp = mtf[g:g + 50]
+            costs = [int(seed[t, grp].sum()) for t in range(nt)]
+            np.add.at(tf[int(np.argmin(costs))], grp, 1)
+        got[java_order] = np.stack([orc.huffman_code_lengths(tf[t].astype(np.int32), alpha) for t in range(nt)])
+    assert not np.array_equal(got[True], got[False])      # the input tells the two readings apart
+    assert np.array_equal(got[True], iters[0][:nt, :alpha])  # the oracle follows the Java original
