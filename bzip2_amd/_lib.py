@@ -25,7 +25,7 @@ SYMBOLS = [
     "bz2hip_last_stats", "bz2hip_last_stats2", "bz2hip_decompress", "bz2hip_decompress_device",
     "bz2hip_compress_device_noalloc", "bz2hip_shard_scan", "bz2hip_shard_chain",
     "bz2hip_shard_compress", "bz2hip_stitch_device", "bz2hip_host_alloc", "bz2hip_host_free",
-    "bz2hip_tie_stats",
+    "bz2hip_tie_stats", "bz2hip_decode_consumed",
 ]
 
 
@@ -121,6 +121,8 @@ def load():
     L.bz2hip_shard_chain.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int, u32p, C.POINTER(C.c_uint64)]
     L.bz2hip_shard_compress.restype = C.c_int
     L.bz2hip_shard_compress.argtypes = [vp, vp, sz, C.POINTER(C.c_uint64), vp, C.c_uint32, u32p]
+    L.bz2hip_decode_consumed.restype = C.c_int
+    L.bz2hip_decode_consumed.argtypes = [vp, C.POINTER(sz)]
     L.bz2hip_tie_stats.restype = C.c_int
     L.bz2hip_tie_stats.argtypes = [vp, vp, vp, vp]
     L.bz2hip_host_alloc.restype = C.c_int
@@ -240,6 +242,12 @@ class Context:
         if rc in (-1, -2, -3):
             self._chk(rc)
         return rc, out[: n.value].tobytes()
+
+    def decode_consumed(self):
+        """input bytes the last successfully decoded stream occupied (concatenated streams continue there)"""
+        n = C.c_size_t(0)
+        self.L.bz2hip_decode_consumed(self.h, C.byref(n))
+        return n.value
 
     def decompress_device(self, d_in_ptr, n, d_out_ptr, cap):
         got = C.c_size_t(0)

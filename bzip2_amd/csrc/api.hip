@@ -1532,6 +1532,12 @@ extern "C" int bz2hip_last_stats3(bz2hip_ctx *c, double *bwt_seconds, uint64_t *
     return BZ2HIP_OK;
 }
 
+extern "C" int bz2hip_decode_consumed(bz2hip_ctx *c, size_t *consumed) {
+    if (!c || !consumed) return BZ2HIP_E_PARAM;
+    *consumed = c->dec_consumed;
+    return BZ2HIP_OK;
+}
+
 extern "C" int bz2hip_tie_stats(bz2hip_ctx *c, uint64_t *replays, uint64_t *reused, uint64_t *cached_keys) {
     if (!c) return BZ2HIP_E_PARAM;
     u64 r = c->st_tie_replays, u = c->st_tie_cached, k = c->tie_cache.size();

@@ -153,6 +153,7 @@ struct bz2hip_ctx {
     size_t stream_chunk = (size_t)64 << 20; // BZ2HIP_STREAM_CHUNK_MIB: streaming flush threshold per GPU
     u64 dec_pass_bytes = 0xfffffff0ull;     // BZ2HIP_DEC_PASS_MIB (tests): decoded bytes written per pass (u32 offsets)
     // decoder workspace, kept between calls (one region, grown on demand)
+    size_t dec_consumed = 0;   // bytes of the input the last successfully decoded stream occupied
     void *dec_region = nullptr;
     size_t dec_region_cap = 0;
     bool fixed_ws = false;   // allocation-free call in progress: workspace carved from the static scratch

@@ -889,6 +889,7 @@ int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size
                    u32 *blocks_out) {
     *produced = 0;
     if (blocks_out) *blocks_out = 0;
+    c->dec_consumed = 0;
     hipStream_t st = c->stream;
     const u64 total_bits = (u64)nbytes * 8u;
     // stream header, S/BZip2InputStream.swift:166-180
@@ -1126,6 +1127,7 @@ int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size
             c->err = "BZip2 stream CRC error";
             return BZ2HIP_E_STREAM_CRC;
         }
+        c->dec_consumed = (size_t)((cur + 80 + 7) / 8); // the trailer is followed by zero padding to a byte
         return BZ2HIP_OK;
     }
     c->err = "BZip2 stream format error";

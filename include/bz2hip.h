@@ -233,6 +233,12 @@ int bz2hip_decompress(bz2hip_ctx *ctx, const uint8_t *in, size_t n, uint8_t *out
 int bz2hip_decompress_device(bz2hip_ctx *ctx, const void *d_in, size_t n, void *d_out, size_t cap,
                              size_t *produced);
 
+/* Input bytes the stream of the last bz2hip_decompress* call occupied (header through stream CRC and
+ * its zero padding), 0 unless it returned BZ2HIP_OK.  The reference's decoder stops at the first
+ * end marker (S/BZip2InputStream.swift:201-242); a front end that wants the bzip2 tool's behaviour
+ * for concatenated streams calls again at in + consumed (python -m bzip2_amd does). */
+int bz2hip_decode_consumed(bz2hip_ctx *ctx, size_t *consumed);
+
 /* ---- profiling (profile=1): accumulated HIP-event time per kernel class --------------- */
 #define BZ2HIP_PROF_MAX 48
 int bz2hip_profile_reset(bz2hip_ctx *ctx);

@@ -127,6 +127,13 @@ def test_cli_roundtrip(tmp_path):
     assert src.read_bytes() == data and not (tmp_path / "sample.bin.bz2").exists()
     out = subprocess.run([sys.executable, "-m", "bzip2_amd", "-c"], input=data, capture_output=True, env=env, cwd=ROOT)
     assert out.returncode == 0 and bz2.decompress(out.stdout) == data
+    # concatenated streams (cat a.bz2 b.bz2 c.bz2), different levels and encoders, trailing garbage
+    parts = [data[:700000], b"", data[700000:], b"tail " * 1000]
+    cat = bz2.compress(parts[0], 3) + out.stdout[:0] + bz2.compress(parts[1], 9) + \
+        subprocess.run([sys.executable, "-m", "bzip2_amd", "-1", "-c"], input=parts[2], capture_output=True, env=env,
+                       cwd=ROOT).stdout + bz2.compress(parts[3], 5) + b"\x00\x00garbage"
+    back = subprocess.run([sys.executable, "-m", "bzip2_amd", "-d", "-c"], input=cat, capture_output=True, env=env, cwd=ROOT)
+    assert back.returncode == 0 and back.stdout == b"".join(parts)
 
 
 def test_chain_longer_than_32bit_offsets_is_written_in_passes(orc):
