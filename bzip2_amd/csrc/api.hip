@@ -13,6 +13,7 @@
 #define DEFAULT_BATCH_BLOCKS 1024
 #define WMAX (1u << 30) // window of input scanned at once (u32 prefix sums stay < 2^32)
 #define STREAM_CHUNK ((size_t)64 << 20) // streaming: input buffered per GPU before a flush
+#define UPLOAD_CHUNK ((size_t)32 << 20) // host-buffer entry points: upload granule scanned as it lands
 
 // ------------------------------------------------------------------ workspace
 // A batch workspace is ONE device region carved into its arrays (256-byte aligned each), so that
@@ -290,6 +291,7 @@ extern "C" int bz2hip_create(bz2hip_ctx **out, const bz2hip_opts *opts) {
         HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->ev_tie, hipEventDisableTiming));
         HIPCHK(hipStreamCreate(&c->stream_tie));
+        HIPCHK(hipStreamCreate(&c->stream_copy));
         // this device's copy of the static scratch (device `dev` is current)
         void *sp = nullptr;
         HIPCHK(hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch)));
@@ -301,6 +303,7 @@ extern "C" int bz2hip_create(bz2hip_ctx **out, const bz2hip_opts *opts) {
         if (c->ev_join) (void)hipEventDestroy(c->ev_join);
         if (c->ev_tie) (void)hipEventDestroy(c->ev_tie);
         if (c->stream_tie) (void)hipStreamDestroy(c->stream_tie);
+        if (c->stream_copy) (void)hipStreamDestroy(c->stream_copy);
         (void)hipStreamDestroy(c->stream);
         (void)hipStreamDestroy(c->stream_other);
         delete c;
@@ -346,6 +349,8 @@ extern "C" void bz2hip_destroy(bz2hip_ctx *c) {
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_tie) (void)hipEventDestroy(c->ev_tie);
     if (c->stream_tie) { (void)hipStreamSynchronize(c->stream_tie); (void)hipStreamDestroy(c->stream_tie); }
+    if (c->stream_copy) { (void)hipStreamSynchronize(c->stream_copy); (void)hipStreamDestroy(c->stream_copy); }
+    for (auto e : c->up_events) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
     (void)hipStreamDestroy(c->stream_other);
     delete c;
@@ -1005,9 +1010,20 @@ extern "C" int bz2hip_compress(bz2hip_ctx *c, const uint8_t *in, size_t n, int l
         }
         size_t bound = bz2hip_compress_bound(n);
         ensure_staging(c, n, bound);
-        if (n) HIPCHK(hipMemcpyAsync(c->h_in, in, n, hipMemcpyHostToDevice, c->stream));
+        if (n && n <= WMAX && n > 2 * UPLOAD_CHUNK) {
+            // one window: the upload is issued chunk by chunk inside the K1 scan (run_scan), so that
+            // the scan of a chunk runs under the transfer of the next
+            c->up.active = true;
+            c->up.host = in;
+            c->up.dev = c->h_in;
+            c->up.n = n;
+            c->up.chunk = UPLOAD_CHUNK;
+        } else if (n) {
+            HIPCHK(hipMemcpyAsync(c->h_in, in, n, hipMemcpyHostToDevice, c->stream));
+        }
         size_t got = 0;
         int rc = bz2hip_compress_device(c, c->h_in, n, level, c->h_out, bound, &got);
+        c->up.active = false;
         if (rc != BZ2HIP_OK) return rc;
         if (got > cap) return fail(c, BZ2HIP_E_CAP, "output buffer too small");
         HIPCHK(hipMemcpy(out, c->h_out, got, hipMemcpyDeviceToHost));

@@ -168,6 +168,24 @@ struct bz2hip_ctx {
     u32 w_maxblocks = 0;
     u32 w_ETPB = 0;          // emit tiles per block slot
     int w_eagg_nb = 0;
+    // host -> device upload in flight (bz2hip_compress): run_scan issues it chunk by chunk on the
+    // copy stream and scans every chunk as it lands
+    struct Upload {
+        bool active = false;
+        const u8 *host = nullptr;
+        u8 *dev = nullptr;
+        size_t n = 0, chunk = 0;
+    } up;
+    hipStream_t stream_copy = nullptr;
+    std::vector<hipEvent_t> up_events;
+    hipEvent_t up_event(size_t k) {
+        while (up_events.size() <= k) {
+            hipEvent_t e;
+            HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            up_events.push_back(e);
+        }
+        return up_events[k];
+    }
     // staging buffers for the host-pointer entry points
     u8 *h_in = nullptr;  size_t h_in_cap = 0;
     u8 *h_out = nullptr; size_t h_out_cap = 0;

@@ -25,8 +25,9 @@ __device__ __forceinline__ u32 enc_rem(u32 r) { return r < 4 ? r : 5u; }
 
 // phase 1: last head position + 1 per tile
 __global__ __launch_bounds__(256) void k1_heads_p1(const u8 *__restrict__ in, u32 n,
-                                                   u32 *__restrict__ agg) {
-    const u32 base = blockIdx.x * K1_TILE;
+                                                   u32 *__restrict__ agg, u32 tile0) {
+    const u32 tile = tile0 + blockIdx.x;
+    const u32 base = tile * K1_TILE;
     __shared__ u32 sm[8];
     u32 last = 0;
     // unconditional (clamped) loads first: 32 byte loads in flight per thread
@@ -44,16 +45,19 @@ __global__ __launch_bounds__(256) void k1_heads_p1(const u8 *__restrict__ in, u3
         if (i < n && (i == 0 || c0[k] != c1[k])) last = i + 1;
     }
     u32 t = block_reduce_max<256>(last, sm);
-    if (threadIdx.x == 0) agg[blockIdx.x] = t;
+    if (threadIdx.x == 0) agg[tile] = t;
 }
 
-// exclusive scans over a flat array of tile aggregates (single workgroup of 1024)
+// exclusive scans over a flat array of tile aggregates (single workgroup of 1024), tiles
+// [first, count): the carry of the tiles before `first` comes in through *total_out (input chunks
+// are scanned as they arrive), and the running total goes back there
 template <bool MAXOP>
-__global__ __launch_bounds__(1024) void k1_scan_tiles(u32 *__restrict__ agg, u32 count,
+__global__ __launch_bounds__(1024) void k1_scan_tiles(u32 *__restrict__ agg, u32 first, u32 count,
                                                       u32 *__restrict__ total_out) {
     __shared__ u32 sm[20];
-    u32 carry = 0;
-    for (u32 t0 = 0; t0 < count; t0 += 1024) {
+    u32 carry = (first && total_out) ? *total_out : 0;
+    __syncthreads();
+    for (u32 t0 = first; t0 < count; t0 += 1024) {
         u32 t = t0 + threadIdx.x;
         u32 v = (t < count) ? agg[t] : 0;
         u32 tot, ex;
@@ -85,8 +89,9 @@ __global__ __launch_bounds__(1024) void k1_scan_tiles(u32 *__restrict__ agg, u32
 __global__ __launch_bounds__(256) void k1_runs(const u8 *__restrict__ in, u32 n,
                                                const u32 *__restrict__ agg_head,
                                                u32 *__restrict__ rs, u32 *__restrict__ agg_c,
-                                               u32 *__restrict__ P) {
-    const u32 base = blockIdx.x * K1_TILE;
+                                               u32 *__restrict__ P, u32 tile0) {
+    const u32 tile = tile0 + blockIdx.x;
+    const u32 base = tile * K1_TILE;
     const int w = wave_id(), lane = lane_id();
     __shared__ u32 wlast[4];
     __shared__ u32 wsum[4];
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(256) void k1_runs(const u8 *__restrict__ in, u32 n,
     }
     if (lane == 0) wlast[w] = last;
     __syncthreads();
-    u32 carry = agg_head[blockIdx.x]; // last head (+1) before this tile
+    u32 carry = agg_head[tile]; // last head (+1) before this tile
     for (int q = 0; q < w; q++) carry = max(carry, wlast[q]);
     u32 cv[16];
     u32 wtot = 0;
@@ -138,7 +143,7 @@ __global__ __launch_bounds__(256) void k1_runs(const u8 *__restrict__ in, u32 n,
     wtot = wave_reduce_add(wtot);
     if (lane == 0) wsum[w] = wtot;
     __syncthreads();
-    if (threadIdx.x == 0) agg_c[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (threadIdx.x == 0) agg_c[tile] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     u32 run = 0;
     for (int q = 0; q < w; q++) run += wsum[q];
 #pragma unroll
@@ -549,17 +554,38 @@ void k1_init_tables(bz2hip_ctx *c) {
 }
 
 // Scan a window of input: fills rs[0..n], P[0..n] (asynchronous; independent of where blocks start).
+// When the window is still on its way from the host (c->up: bz2hip_compress), it is uploaded in
+// chunks on the copy stream and every chunk is scanned as soon as it has landed, so the transfer
+// of chunk k + 1 runs under the scan of chunk k.
 void run_scan(bz2hip_ctx *c, const u8 *d_in, u32 n, u32 *d_rs, u32 *d_P, u32 *d_agg1, u32 *d_agg2) {
     Batch &B = c->batch;
     const u32 tiles = (n + K1_TILE - 1) / K1_TILE;
     ProfScope ps(c, P_RLE1_SCAN, 0);
-    k1_heads_p1<<<tiles, 256, 0, c->stream>>>(d_in, n, d_agg1);
-    KCHECK();
-    k1_scan_tiles<true><<<1, 1024, 0, c->stream>>>(d_agg1, tiles, nullptr);
-    KCHECK();
-    k1_runs<<<tiles, 256, 0, c->stream>>>(d_in, n, d_agg1, d_rs, d_agg2, d_P);
-    KCHECK();
-    k1_scan_tiles<false><<<1, 1024, 0, c->stream>>>(d_agg2, tiles, B.ctl + 8);
+    const bool chunked = c->up.active && c->up.dev == d_in && c->up.n == n;
+    const size_t chunk = chunked ? c->up.chunk : (size_t)n;
+    u32 *carry_max = B.ctl + 10; // running last-head carry between chunks
+    size_t k = 0;
+    for (size_t off = 0; off < n; off += chunk, k++) {
+        const size_t len = std::min<size_t>(chunk, n - off);
+        const u32 t0 = (u32)(off / K1_TILE), t1 = (u32)((off + len + K1_TILE - 1) / K1_TILE);
+        if (chunked) {
+            HIPCHK(hipMemcpyAsync(c->up.dev + off, c->up.host + off, len, hipMemcpyHostToDevice, c->stream_copy));
+            hipEvent_t e = c->up_event(k);
+            HIPCHK(hipEventRecord(e, c->stream_copy));
+            HIPCHK(hipStreamWaitEvent(c->stream, e, 0));
+        }
+        // n is passed as the bytes present so far: the last tile of a chunk clamps at its end, and
+        // chunks are multiples of the tile, so every tile sees exactly its own bytes
+        const u32 upto = (u32)(off + len);
+        k1_heads_p1<<<t1 - t0, 256, 0, c->stream>>>(d_in, upto, d_agg1, t0);
+        KCHECK();
+        k1_scan_tiles<true><<<1, 1024, 0, c->stream>>>(d_agg1, t0, t1, carry_max);
+        KCHECK();
+        k1_runs<<<t1 - t0, 256, 0, c->stream>>>(d_in, upto, d_agg1, d_rs, d_agg2, d_P, t0);
+        KCHECK();
+    }
+    c->up.active = false;
+    k1_scan_tiles<false><<<1, 1024, 0, c->stream>>>(d_agg2, 0, tiles, B.ctl + 8);
     KCHECK();
     k1_sentinels<<<1, 64, 0, c->stream>>>(d_rs, d_P, d_agg2, n, B.ctl + 8);
     KCHECK();
