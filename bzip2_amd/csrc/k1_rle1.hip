@@ -287,10 +287,25 @@ __global__ __launch_bounds__(64) void k1_split(const u32 *__restrict__ rs,
                 e = re0 + 1; // the first run alone overfills: refused right after the next head
             } else {
                 const u32 thr = limit - enc0 + (have_p ? p_re0p1 : P(re0 + 1));
-                // blocks of one kind of data are about equally long: bracket around the last length
+                // blocks of one kind of data are about equally long.  When the last block was as long as
+                // the one before (run-free data: always bs - 4 bytes), one probe of the 64 positions
+                // around "as long again" settles this block in a single dependent load.
+                bool done = false;
+                if (plen && perr == 0) {
+                    const u32 c = s + plen;
+                    if (c > re0 + 33u && (u64)c + 31ull <= (u64)hi) {
+                        const u32 idx = c - 32u + (u32)lane_id();
+                        const u64 m = __ballot(P(idx) > thr);
+                        if (m && !(m & 1ull)) { // P(c - 32) <= thr < P(some probe): the first such probe
+                            e = c - 32u + (u32)(__ffsll((unsigned long long)m) - 1);
+                            done = true;
+                        }
+                    }
+                }
+                // otherwise bracket around the last length
                 u32 nlo = 0, nhi = 0;
                 bool br = false;
-                if (plen) {
+                if (!done && plen) {
                     // as wide as the last prediction was wrong (x4), at least 1.5 % of the length
                     const u32 half = min(max(2048u, 4u * perr + plen / 64u), max(2048u, plen / 2u));
                     const u32 c = s + plen;
@@ -298,8 +313,10 @@ __global__ __launch_bounds__(64) void k1_split(const u32 *__restrict__ rs,
                     const u32 hi2 = (u32)min((u64)hi, (u64)c + half);
                     if (lo2 < hi2) br = wave_bracket(P, lo2, hi2, thr, &nlo, &nhi);
                 }
-                e = br ? wave_search_gt(P, nlo, nhi, thr, true) : wave_search_gt(P, re0, hi, thr);
-                if (e > hi) e = (hi == n) ? n : hi; // not expected when hi < n
+                if (!done) {
+                    e = br ? wave_search_gt(P, nlo, nhi, thr, true) : wave_search_gt(P, re0, hi, thr);
+                    if (e > hi) e = (hi == n) ? n : hi; // not expected when hi < n
+                }
             }
         }
         cnt++;
@@ -503,20 +520,50 @@ __global__ __launch_bounds__(256) void k1_crc_p1(const u8 *__restrict__ in,
     if (threadIdx.x == 0) cagg[(size_t)b * ETPB + blockIdx.x] = sm[0] ^ sm[1] ^ sm[2] ^ sm[3];
 }
 
-__global__ void k1_crc_p2(const u32 *__restrict__ starts, const u32 *__restrict__ cagg,
-                          u32 *__restrict__ crc, u32 nb, u32 ETPB) {
-    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+// Combines the tile CRCs of a block: crc = (init * x^(8 len) + sum_t raw_t * x^(8 * bytes after tile t)) ^ ~0.
+// One wave per block: every lane folds a contiguous stretch of tiles (Horner over whole tiles:
+// one multiplication by x^(8*4096) per tile), then the 64 partial values are combined with the
+// power that belongs to the bytes after each lane's stretch.
+__device__ __forceinline__ u32 xpow_bytes(u32 nbytes) { // x^(8 nbytes) mod P, nbytes < 2^32
+    // x^(8 nbytes) = (x^(8*4096))^(nbytes / 4096) * x^(8 (nbytes % 4096))
+    u32 r = gfmul(c_xpow16[(nbytes & 4095u) >> 4], c_xpow1[nbytes & 15u]);
+    u32 q = nbytes >> 12;
+    u32 base = c_xpow16[256];
+    while (q) {
+        if (q & 1u) r = gfmul(r, base);
+        base = gfmul(base, base);
+        q >>= 1;
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(64) void k1_crc_p2(const u32 *__restrict__ starts, const u32 *__restrict__ cagg,
+                                                u32 *__restrict__ crc, u32 nb, u32 ETPB) {
+    const u32 b = blockIdx.x;
     if (b >= nb) return;
+    const int lane = lane_id();
     const u32 len = starts[b + 1] - starts[b];
     const u32 tiles = (len + K1_TILE - 1) / K1_TILE;
+    const u32 per = (tiles + 63) / 64;
+    const u32 t0 = min(tiles, (u32)lane * per), t1 = min(tiles, t0 + per);
     const u32 xfull = c_xpow16[256]; // x^(8*4096)
-    u32 acc = 0xffffffffu;
-    for (u32 t = 0; t < tiles; t++) {
-        u32 tlen = min((u32)K1_TILE, len - t * K1_TILE);
-        u32 mult = (tlen == K1_TILE) ? xfull : gfmul(c_xpow16[tlen >> 4], c_xpow1[tlen & 15]);
+    // this lane's stretch as if it stood alone: every tile but the block's last is full
+    u32 acc = 0;
+    u32 bytes = 0; // bytes in [t0, t1)
+    for (u32 t = t0; t < t1; t++) {
+        const u32 tlen = min((u32)K1_TILE, len - t * K1_TILE);
+        const u32 mult = (tlen == K1_TILE) ? xfull : gfmul(c_xpow16[tlen >> 4], c_xpow1[tlen & 15]);
         acc = gfmul(acc, mult) ^ cagg[(size_t)b * ETPB + t];
+        bytes += tlen;
     }
-    crc[b] = ~acc;
+    // shift by the bytes that follow the stretch
+    const u32 before = min(len, t0 * K1_TILE);
+    const u32 after = len - before - bytes;
+    if (t1 > t0) acc = gfmul(acc, xpow_bytes(after));
+    else acc = 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc ^= __shfl_xor(acc, d, 64);
+    if (lane == 0) crc[b] = ~(acc ^ gfmul(0xffffffffu, xpow_bytes(len)));
 }
 
 // ---------------------------------------------------------------- drivers
@@ -627,7 +674,7 @@ void run_crc_blocks(bz2hip_ctx *c, const u8 *d_data, const u32 *d_starts, int nb
         k1_crc_p1<<<dim3(tiles, nb), 256, 0, c->stream>>>(d_data, d_starts, d_cagg, ETPB);
         KCHECK();
     }
-    k1_crc_p2<<<(nb + 63) / 64, 64, 0, c->stream>>>(d_starts, d_cagg, d_crc, nb, ETPB);
+    k1_crc_p2<<<nb, 64, 0, c->stream>>>(d_starts, d_cagg, d_crc, nb, ETPB);
     KCHECK();
 }
 
@@ -642,7 +689,7 @@ void run_rle1_emit(bz2hip_ctx *c, const u8 *d_in, const u32 *d_rs, const u32 *d_
     {
         k1_crc_p1<<<grid, 256, 0, c->stream_other>>>(d_in, d_starts + b0, c->w_cagg, ETPB);
         KCHECK();
-        k1_crc_p2<<<(nb + 63) / 64, 64, 0, c->stream_other>>>(d_starts + b0, c->w_cagg, B.crc, nb, ETPB);
+        k1_crc_p2<<<nb, 64, 0, c->stream_other>>>(d_starts + b0, c->w_cagg, B.crc, nb, ETPB);
         KCHECK();
         HIPCHK(hipEventRecord(c->crc_done, c->stream_other));
     }
