@@ -33,8 +33,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 KERNEL = {"radix_scatter": "k2_radix_scatter", "radix_hist": "k2_radix_hist",
           "bwt_keys": "k2_keys", "bwt_ssort": "k2_ssort", "mtf_replay": "k3_mtf_replay"}
-PMC_NAME = {"k2_ssort": "void k2_ssort<0>", "k2_radix_scatter": "void k2_radix_scatter<false>",
-            "k2_radix_hist": "void k2_radix_hist<false>"}
+PMC_NAME = {"k2_ssort": ["void k2_ssort<0>"],
+            "k2_radix_scatter": ["void k2_radix_scatter<false, 8, true>", "void k2_radix_scatter<false>"],
+            "k2_radix_hist": ["void k2_radix_hist<false, 8>", "void k2_radix_hist<false>"]}
 
 
 def load_pmc():
@@ -271,10 +272,11 @@ def main():
             pmc_file, pmc = load_pmc()
             if not (world == 1 and seg == 256 and level == 9):
                 pmc_file, pmc = None, {}  # the PMC passes were made on the N = 1 headline workload
-            try:
-                traffic = pmc[PMC_NAME.get(KERNEL[dom], KERNEL[dom])]["hbm_bytes_per_call"]
-            except KeyError:
-                traffic = None
+            traffic = None
+            for nm in PMC_NAME.get(KERNEL[dom], [KERNEL[dom]]):
+                if nm in pmc:
+                    traffic = pmc[nm]["hbm_bytes_per_call"]
+                    break
             res["roofline"] = {"bound": "hbm", "kernel": KERNEL[dom],
                                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
