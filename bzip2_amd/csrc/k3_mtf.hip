@@ -39,41 +39,32 @@ __device__ __forceinline__ void build_symbol_map(const u32 *__restrict__ present
 // s is the number of symbols with a later time, i.e. 4 compares + 4 scalar popcounts, and the
 // update is one register of one lane.  No list shifting: ~10 instructions per run head instead
 // of ~25.  The entry state (a list) becomes times 255 - position.
-__global__ __launch_bounds__(256) void k3_mtf_replay(const u8 *__restrict__ bwt,
-                                                     const u32 *__restrict__ nArr,
-                                                     const u32 *__restrict__ present,
-                                                     const u8 *__restrict__ mtfrec,
-                                                     u8 *__restrict__ mtfpos, u32 S, u32 CPB) {
-    const u32 b = blockIdx.y;
-    const u32 n = nArr[b];
-    __shared__ u8 smap[256];
-    __shared__ u32 ts[MTF_WG_CHUNKS][256];
-    build_symbol_map(present + b * 8, smap);
-    __syncthreads();
-    const int w = wave_id(), lane = lane_id();
-    const u32 c = blockIdx.x * MTF_WG_CHUNKS + w;
-    const u32 cbase = c * MTF_CHUNK;
-    if (cbase >= n) return;
-    const u8 *src = bwt + (size_t)b * S;
-    const u32 cend = min(cbase + MTF_CHUNK, n);
+// NSYM = dense symbol ids per lane (64 * NSYM >= alphabet size): 1, 2 or 4.  Symbols that do not
+// occur sit at the end of every entry list (the recency operator only moves present symbols to the
+// front) and keep the lowest times, so they never count towards a position: a block of <= 128
+// symbols (text) needs 2 compares + 2 popcounts per run head, one of <= 64 (DNA, Markov) 1.
+template <int NSYM>
+__device__ __forceinline__ void mtf_replay_body(const u8 *__restrict__ src, u32 cbase, u32 cend,
+                                                const u8 *smap, u32 *tsrow, u32 st,
+                                                u8 *__restrict__ dst) {
+    const int lane = lane_id();
     u8 rowv[MTF_CHUNK / 64];
 #pragma unroll
     for (int r = 0; r < MTF_CHUNK / 64; r++) rowv[r] = src[cbase + r * 64 + lane];
     // entry list -> times
-    {
-        const u32 st = ((const u32 *)(mtfrec + ((size_t)b * CPB + c) * 256))[lane];
 #pragma unroll
-        for (int k = 0; k < 4; k++) ts[w][(st >> (8 * k)) & 255u] = 255u - (u32)(lane * 4 + k);
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-    }
-    u32 L0 = ts[w][lane * 4 + 0], L1 = ts[w][lane * 4 + 1], L2 = ts[w][lane * 4 + 2], L3 = ts[w][lane * 4 + 3];
-    // ts[w][] stays a mirror of the registers: the time of the head's symbol is read from it (one
+    for (int k = 0; k < 4; k++) tsrow[(st >> (8 * k)) & 255u] = 255u - (u32)(lane * 4 + k);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    u32 L[NSYM];
+#pragma unroll
+    for (int k = 0; k < NSYM; k++) L[k] = tsrow[lane * NSYM + k];
+    // tsrow[] stays a mirror of the registers: the time of the head's symbol is read from it (one
     // uniform LDS read, issued one head ahead: consecutive heads are different symbols), so no
-    // register has to be selected by s & 3; the update compares all four ids of the lane with s
-    const u32 id0 = (u32)lane * 4u;
+    // register has to be selected by the symbol; the update compares all ids of the lane with s
+    const u32 id0 = (u32)lane * (u32)NSYM;
     typedef __attribute__((address_space(3))) u32 lds_u32;
-    lds_u32 *const tsw = (lds_u32 *)&ts[w][0];
+    lds_u32 *const tsw = (lds_u32 *)tsrow;
     u32 prev = 0xffffffffu;
     u32 now = 256;
 #pragma unroll
@@ -86,7 +77,7 @@ __global__ __launch_bounds__(256) void k3_mtf_replay(const u8 *__restrict__ bwt,
         const u32 left = (u32)__builtin_amdgcn_update_dpp((int)prev, (int)sym, 0x138, 0xf, 0xf, false);
         u64 heads = __ballot(j < cend && sym != left);
         if (heads) {
-            // one head: (iA, pA = &ts[w][sA], tA) is the head being placed; the next head's index,
+            // one head: (iA, pA = &ts[sA], tA) is the head being placed; the next head's index,
             // mirror slot and time are fetched first.  Two copies with the roles swapped, so that
             // nothing has to be moved between iterations.
 #define MTF_HEAD(iA, sA, pA, tA, iB, sB, pB, tB)                                                       \
@@ -97,12 +88,9 @@ __global__ __launch_bounds__(256) void k3_mtf_replay(const u8 *__restrict__ bwt,
     pB = tsw + sB;                                                                                     \
     tB = *pB;                                                                                          \
     {                                                                                                  \
-        const u32 pos = (u32)__popcll(__ballot(L0 > tA)) + (u32)__popcll(__ballot(L1 > tA)) +          \
-                        (u32)__popcll(__ballot(L2 > tA)) + (u32)__popcll(__ballot(L3 > tA));           \
-        L0 = (id0 == sA) ? now : L0;                                                                   \
-        L1 = (id0 + 1u == sA) ? now : L1;                                                              \
-        L2 = (id0 + 2u == sA) ? now : L2;                                                              \
-        L3 = (id0 + 3u == sA) ? now : L3;                                                              \
+        u32 pos = 0;                                                                                   \
+        _Pragma("unroll") for (int k = 0; k < NSYM; k++) pos += (u32)__popcll(__ballot(L[k] > tA));    \
+        _Pragma("unroll") for (int k = 0; k < NSYM; k++) L[k] = (id0 + (u32)k == sA) ? now : L[k];     \
         *pA = now; /* every lane, same slot, same value: cheaper than narrowing exec */               \
         if (lane == iA) mypos = pos;                                                                   \
         now++;                                                                                         \
@@ -120,8 +108,35 @@ __global__ __launch_bounds__(256) void k3_mtf_replay(const u8 *__restrict__ bwt,
 #undef MTF_HEAD
         }
         prev = __builtin_amdgcn_readlane(sym, 63);
-        if (j < cend) mtfpos[(size_t)b * S + j] = (u8)mypos;
+        if (j < cend) dst[j] = (u8)mypos;
     }
+}
+
+__global__ __launch_bounds__(256) void k3_mtf_replay(const u8 *__restrict__ bwt,
+                                                     const u32 *__restrict__ nArr,
+                                                     const u32 *__restrict__ present,
+                                                     const u8 *__restrict__ mtfrec,
+                                                     u8 *__restrict__ mtfpos, u32 S, u32 CPB) {
+    const u32 b = blockIdx.y;
+    const u32 n = nArr[b];
+    __shared__ u8 smap[256];
+    __shared__ u32 ts[MTF_WG_CHUNKS][256];
+    build_symbol_map(present + b * 8, smap);
+    __syncthreads();
+    const int w = wave_id(), lane = lane_id();
+    const u32 c = blockIdx.x * MTF_WG_CHUNKS + w;
+    const u32 cbase = c * MTF_CHUNK;
+    if (cbase >= n) return;
+    const u8 *src = bwt + (size_t)b * S;
+    const u32 cend = min(cbase + MTF_CHUNK, n);
+    u32 uniq = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) uniq += __popc(present[b * 8 + q]);
+    const u32 st = ((const u32 *)(mtfrec + ((size_t)b * CPB + c) * 256))[lane];
+    u8 *dst = mtfpos + (size_t)b * S;
+    if (uniq <= 64) mtf_replay_body<1>(src, cbase, cend, smap, &ts[w][0], st, dst);
+    else if (uniq <= 128) mtf_replay_body<2>(src, cbase, cend, smap, &ts[w][0], st, dst);
+    else mtf_replay_body<4>(src, cbase, cend, smap, &ts[w][0], st, dst);
 }
 
 // Recency list of a chunk without running the MTF: last occurrence of every symbol (LDS
