@@ -63,6 +63,8 @@ static size_t layout_batch(Batch &N, int level, int nb_blocks, u8 *base) {
     N.periodic = A.get<u32>(nb);
     N.mtfrec = A.get<u8>(nb * (S / MTF_CHUNK) * 256);
     N.mtfcnt = A.get<u32>(nb * (S / MTF_CHUNK));
+    N.mtfgrp = A.get<u8>(nb * 32 * 256);
+    N.mtfglen = A.get<u32>(nb * 32);
     N.mtfpos = A.get<u8>(nb * S);
     N.r2agg = A.get<u32>(nb * N.TPB * 4);
     N.mtf = A.get<u16>(nb * S2);

@@ -90,6 +90,8 @@ struct Batch {
     // MTF / RLE2
     u8 *mtfrec = nullptr;     // [NB][chunks][256] recency lists, then entry states
     u32 *mtfcnt = nullptr;    // [NB][chunks]
+    u8 *mtfgrp = nullptr;     // [NB][32][256] group recency lists, then group entry states
+    u32 *mtfglen = nullptr;   // [NB][32]
     u8 *mtfpos = nullptr;     // [NB][S]
     u32 *r2agg = nullptr;     // [NB][TPB][4] tile summaries (lz, tz, inner, allzero) -> offsets
     u16 *mtf = nullptr;       // [NB][S+?]  (slot size S2 = S + 64 halfwords)

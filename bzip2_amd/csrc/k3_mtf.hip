@@ -197,72 +197,146 @@ __global__ __launch_bounds__(256) void k3_mtf_recency(const u8 *__restrict__ bwt
     if (lane == 0) mtfcnt[(size_t)b * CPB + c] = d;
 }
 
-// one wave per block: turn recency lists into entry states, in place
-__global__ __launch_bounds__(64) void k3_mtf_compose(const u32 *__restrict__ nArr,
-                                                     u8 *__restrict__ mtfrec,
-                                                     const u32 *__restrict__ mtfcnt, u32 CPB) {
-    const u32 b = blockIdx.x;
-    const u32 n = nArr[b];
-    const u32 chunks = (n + MTF_CHUNK - 1) / MTF_CHUNK;
+// Recency lists -> entry states.  The operator "state after = recency list ++ (state before without
+// those symbols)" is associative, so the serial walk over a block's ~880 chunks is cut in MTF_GROUPS
+// groups: (A) every group folds its chunks into one recency list, (B) one wave per block walks the
+// groups' lists, (C) every group walks its chunks from its entry state and stores each chunk's
+// entry state in place.  Serial depth ~28 + 32 + 28 steps instead of ~880.
+#define MTF_GROUPS 32
+
+// st[0..len) := rec[0..d) ++ (st[0..len) without those symbols); returns the new length (one wave)
+__device__ __forceinline__ u32 mtf_compose_step(u8 *st, u8 *nst, u8 *flag, u32 rec, u32 d, u32 len) {
     const int lane = lane_id();
-    __shared__ u8 st[256];
-    __shared__ u8 nst[256];
-    __shared__ u8 flag[256];
-    ((u32 *)st)[lane] = identity_list();
+    ((u32 *)flag)[lane] = 0;
     __syncthreads();
-    // The walk is serial, but the recency lists do not depend on it: fetch them 8 chunks at a
-    // time (independent loads) so that a step costs LDS time, not a global-memory round trip.
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        u32 p = lane * 4 + k;
+        if (p < d) {
+            u8 v = (u8)(rec >> (8 * k));
+            flag[v] = 1;
+            nst[p] = v;
+        }
+    }
+    __syncthreads();
+    u32 cur = ((u32 *)st)[lane];
+    u32 keepcnt = 0;
+    bool keep[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        keep[k] = ((u32)(lane * 4 + k) < len) && flag[(cur >> (8 * k)) & 255u] == 0;
+        keepcnt += keep[k] ? 1u : 0u;
+    }
+    u32 inc = wave_incl_scan_add(keepcnt);
+    u32 o = d + inc - keepcnt;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (keep[k]) nst[o++] = (u8)(cur >> (8 * k));
+    }
+    const u32 newlen = d + (u32)__builtin_amdgcn_readlane((int)inc, 63);
+    __syncthreads();
+    ((u32 *)st)[lane] = ((u32 *)nst)[lane];
+    __syncthreads();
+    return newlen;
+}
+
+// (A) one wave per (group, block): the group's chunks folded into one recency list
+__global__ __launch_bounds__(64) void k3_mtf_group(const u32 *__restrict__ nArr,
+                                                   const u8 *__restrict__ mtfrec,
+                                                   const u32 *__restrict__ mtfcnt, u8 *__restrict__ grec,
+                                                   u32 *__restrict__ glen, u32 CPB) {
+    const u32 b = blockIdx.y, g = blockIdx.x;
+    const u32 chunks = (nArr[b] + MTF_CHUNK - 1) / MTF_CHUNK;
+    const u32 per = (chunks + MTF_GROUPS - 1) / MTF_GROUPS;
+    const u32 c0 = g * per, c1 = min(chunks, c0 + per);
+    const int lane = lane_id();
+    __shared__ u8 st[256], nst[256], flag[256];
+    ((u32 *)st)[lane] = 0;
+    __syncthreads();
+    u32 len = 0;
     constexpr int PF = 8;
-    for (u32 c0 = 0; c0 < chunks; c0 += PF) {
+    for (u32 cb = c0; cb < c1; cb += PF) {
         u32 recs[PF], ds[PF];
 #pragma unroll
         for (int q = 0; q < PF; q++) {
-            const u32 c = c0 + q;
+            const u32 c = cb + q;
             recs[q] = 0;
             ds[q] = 0;
-            if (c < chunks) {
+            if (c < c1) {
                 recs[q] = ((const u32 *)(mtfrec + ((size_t)b * CPB + c) * 256))[lane];
                 ds[q] = mtfcnt[(size_t)b * CPB + c];
             }
         }
 #pragma unroll
         for (int q = 0; q < PF; q++) {
-            const u32 c = c0 + q;
-            if (c >= chunks) break;
+            if (cb + q >= c1) break;
+            len = mtf_compose_step(st, nst, flag, recs[q], ds[q], len);
+        }
+    }
+    ((u32 *)(grec + ((size_t)b * MTF_GROUPS + g) * 256))[lane] = ((u32 *)st)[lane];
+    if (lane == 0) glen[b * MTF_GROUPS + g] = len;
+}
+
+// (B) one wave per block: entry state of every group (written over the group's list)
+__global__ __launch_bounds__(64) void k3_mtf_gscan(u8 *__restrict__ grec, const u32 *__restrict__ glen) {
+    const u32 b = blockIdx.x;
+    const int lane = lane_id();
+    __shared__ u8 st[256], nst[256], flag[256];
+    ((u32 *)st)[lane] = identity_list();
+    __syncthreads();
+    u32 recs[MTF_GROUPS], ds[MTF_GROUPS];
+#pragma unroll
+    for (int g = 0; g < MTF_GROUPS; g++) {
+        recs[g] = ((const u32 *)(grec + ((size_t)b * MTF_GROUPS + g) * 256))[lane];
+        ds[g] = glen[b * MTF_GROUPS + g];
+    }
+#pragma unroll
+    for (int g = 0; g < MTF_GROUPS; g++) {
+        ((u32 *)(grec + ((size_t)b * MTF_GROUPS + g) * 256))[lane] = ((u32 *)st)[lane];
+        (void)mtf_compose_step(st, nst, flag, recs[g], ds[g], 256);
+    }
+}
+
+// (C) one wave per (group, block): turn the chunks' recency lists into entry states, in place
+__global__ __launch_bounds__(64) void k3_mtf_compose(const u32 *__restrict__ nArr,
+                                                     u8 *__restrict__ mtfrec,
+                                                     const u32 *__restrict__ mtfcnt,
+                                                     const u8 *__restrict__ grec, u32 CPB) {
+    const u32 b = blockIdx.y, g = blockIdx.x;
+    const u32 n = nArr[b];
+    const u32 chunks = (n + MTF_CHUNK - 1) / MTF_CHUNK;
+    const u32 per = (chunks + MTF_GROUPS - 1) / MTF_GROUPS;
+    const u32 c0 = g * per, c1 = min(chunks, c0 + per);
+    if (c0 >= c1) return;
+    const int lane = lane_id();
+    __shared__ u8 st[256];
+    __shared__ u8 nst[256];
+    __shared__ u8 flag[256];
+    ((u32 *)st)[lane] = ((const u32 *)(grec + ((size_t)b * MTF_GROUPS + g) * 256))[lane];
+    __syncthreads();
+    // The walk is serial, but the recency lists do not depend on it: fetch them 8 chunks at a
+    // time (independent loads) so that a step costs LDS time, not a global-memory round trip.
+    constexpr int PF = 8;
+    for (u32 cb = c0; cb < c1; cb += PF) {
+        u32 recs[PF], ds[PF];
+#pragma unroll
+        for (int q = 0; q < PF; q++) {
+            const u32 c = cb + q;
+            recs[q] = 0;
+            ds[q] = 0;
+            if (c < c1) {
+                recs[q] = ((const u32 *)(mtfrec + ((size_t)b * CPB + c) * 256))[lane];
+                ds[q] = mtfcnt[(size_t)b * CPB + c];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PF; q++) {
+            const u32 c = cb + q;
+            if (c >= c1) break;
             u32 *slot = (u32 *)(mtfrec + ((size_t)b * CPB + c) * 256);
-            const u32 rec = recs[q]; // recency list of chunk c (first d entries valid)
-            const u32 d = ds[q];
             slot[lane] = ((u32 *)st)[lane]; // entry state of chunk c
-            if (c + 1 == chunks) break;
-            ((u32 *)flag)[lane] = 0;
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                u32 p = lane * 4 + k;
-                if (p < d) {
-                    u8 v = (u8)(rec >> (8 * k));
-                    flag[v] = 1;
-                    nst[p] = v;
-                }
-            }
-            __syncthreads();
-            u32 cur = ((u32 *)st)[lane];
-            u32 keepcnt = 0;
-            bool keep[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                keep[k] = flag[(cur >> (8 * k)) & 255u] == 0;
-                keepcnt += keep[k] ? 1u : 0u;
-            }
-            u32 inc = wave_incl_scan_add(keepcnt);
-            u32 o = d + inc - keepcnt;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (keep[k]) nst[o++] = (u8)(cur >> (8 * k));
-            }
-            __syncthreads();
-            ((u32 *)st)[lane] = ((u32 *)nst)[lane];
-            __syncthreads();
+            if (c + 1 == c1) break;
+            (void)mtf_compose_step(st, nst, flag, recs[q], ds[q], 256);
         }
     }
 }
@@ -508,7 +582,11 @@ void run_mtf(bz2hip_ctx *c, int nb, u32 maxn) {
     }
     {
         ProfScope ps(c, P_MTF_COMPOSE);
-        k3_mtf_compose<<<nb, 64, 0, c->stream>>>(B.n, B.mtfrec, B.mtfcnt, CPB);
+        k3_mtf_group<<<dim3(MTF_GROUPS, nb), 64, 0, c->stream>>>(B.n, B.mtfrec, B.mtfcnt, B.mtfgrp, B.mtfglen, CPB);
+        KCHECK();
+        k3_mtf_gscan<<<nb, 64, 0, c->stream>>>(B.mtfgrp, B.mtfglen);
+        KCHECK();
+        k3_mtf_compose<<<dim3(MTF_GROUPS, nb), 64, 0, c->stream>>>(B.n, B.mtfrec, B.mtfcnt, B.mtfgrp, CPB);
         KCHECK();
     }
     {
