@@ -238,14 +238,27 @@ __global__ __launch_bounds__(256) void k2_radix_scan(const u32 *__restrict__ cnt
     u32 run[PER];
 #pragma unroll
     for (int q = 0; q < PER; q++) run[q] = 0;
-    for (u32 t = 0; t < tiles; t++) {
+    // 8 tiles at a time: the loads of a chunk are issued together (the walk is a dependent chain
+    // only through the running sums)
+    constexpr int TB = 8;
+    for (u32 t0 = 0; t0 < tiles; t0 += TB) {
+        u32 cv[TB][PER];
 #pragma unroll
-        for (int q = 0; q < PER; q++) {
-            // digit = q * 256 + thread: coalesced over threads
-            u32 *th = tilehist + ((size_t)b * TPB + t) * RB + q * 256 + threadIdx.x;
-            u32 c = *th;
-            *th = run[q];
-            run[q] += c;
+        for (int k = 0; k < TB; k++)
+#pragma unroll
+            for (int q = 0; q < PER; q++) {
+                const u32 t = min(t0 + (u32)k, tiles - 1u);
+                // digit = q * 256 + thread: coalesced over threads
+                cv[k][q] = tilehist[((size_t)b * TPB + t) * RB + q * 256 + threadIdx.x];
+            }
+#pragma unroll
+        for (int k = 0; k < TB; k++) {
+            if (t0 + (u32)k >= tiles) break;
+#pragma unroll
+            for (int q = 0; q < PER; q++) {
+                tilehist[((size_t)b * TPB + t0 + k) * RB + q * 256 + threadIdx.x] = run[q];
+                run[q] += cv[k][q];
+            }
         }
     }
     // exclusive scan over digits in digit order: digit = q * 256 + thread
