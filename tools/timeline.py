@@ -47,3 +47,11 @@ for m in marks:
         if n.startswith(m):
             print(f"  first {m:16s} at {(s - t0) / 1e6:7.3f} ms")
             break
+
+# optional: list every kernel of a time window (ms from the step start): TL_FROM / TL_TO
+import os
+if os.environ.get("TL_FROM"):
+    a, b = float(os.environ["TL_FROM"]) * 1e6, float(os.environ.get("TL_TO", "1e9")) * 1e6
+    for s_, e_, n_ in step:
+        if a <= s_ - t0 <= b:
+            print(f"  {(s_ - t0) / 1e6:8.3f} +{(e_ - s_) / 1e3:8.1f} us  {n_[:50]}")
