@@ -390,40 +390,53 @@ __global__ __launch_bounds__(64) void k4_plan(const u32 *__restrict__ nsel,
     }
 }
 
-// bit offsets of blocks: single workgroup.  If per_block (stage API) every block starts at
-// b*bits_stride*8, else blocks abut starting at first_bit.
-__global__ void k4_offsets(const u64 *__restrict__ hdr, u64 *__restrict__ bitoff, u32 nb,
-                           u64 first_bit, int per_block, u64 stride_bits) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    u64 pos = first_bit;
-    for (u32 b = 0; b < nb; b++) {
-        u64 tot = hdr[b * 4] + hdr[b * 4 + 1] + hdr[b * 4 + 2] + hdr[b * 4 + 3];
-        if (per_block) {
-            bitoff[b] = (u64)b * stride_bits;
+// bit offsets of blocks: single workgroup (a scan over the blocks' bit totals).  If per_block
+// (stage API) every block starts at b*stride_bits, else blocks abut starting at first_bit.
+__global__ __launch_bounds__(256) void k4_offsets(const u64 *__restrict__ hdr, u64 *__restrict__ bitoff,
+                                                  u32 nb, u64 first_bit, int per_block,
+                                                  u64 stride_bits) {
+    __shared__ u64 wsum[4];
+    __shared__ u64 carry;
+    const int lane = lane_id(), w = wave_id();
+    if (threadIdx.x == 0) carry = first_bit;
+    __syncthreads();
+    for (u32 b0 = 0; b0 < nb; b0 += 256) {
+        const u32 b = b0 + threadIdx.x;
+        u64 tot = 0;
+        if (b < nb) tot = hdr[b * 4] + hdr[b * 4 + 1] + hdr[b * 4 + 2] + hdr[b * 4 + 3];
+        // wave scan in 32 bits: a block is < 2^25 bits, 64 of them fit
+        const u32 inc = wave_incl_scan_add((u32)tot);
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        u64 base = carry;
+        for (int q = 0; q < w; q++) base += wsum[q];
+        if (b < nb) {
+            bitoff[b] = per_block ? (u64)b * stride_bits : base + inc - tot;
             bitoff[nb + 1 + b] = tot;
-        } else {
-            bitoff[b] = pos;
-            bitoff[nb + 1 + b] = tot;
-            pos += tot;
         }
+        __syncthreads();
+        if (threadIdx.x == 255) carry = base + inc;
+        __syncthreads();
     }
-    bitoff[nb] = pos;
+    if (threadIdx.x == 0) bitoff[nb] = per_block ? first_bit : carry;
 }
 
 // ------------------------------------------------------------------ header, selectors, tables
-// one wave per block
-__global__ __launch_bounds__(64) void k4_write_header(
+// one workgroup of 4 waves per block: thread 0 the fixed fields, all threads the selectors, wave
+// w the coding tables w and w + 4 with the lanes over runs of consecutive symbols
+__global__ __launch_bounds__(256) void k4_write_header(
     const u32 *__restrict__ nsel, const u32 *__restrict__ ntables, const u32 *__restrict__ alphaArr,
     const u32 *__restrict__ present, const u32 *__restrict__ crc, const u32 *__restrict__ orig,
     const u8 *__restrict__ selpos, const u8 *__restrict__ hlen, const u64 *__restrict__ hdr,
-    const u64 *__restrict__ bitoff, u32 *__restrict__ out) {
+    const u64 *__restrict__ tblbits, const u64 *__restrict__ bitoff, u32 *__restrict__ out) {
     const u32 b = blockIdx.x;
-    const int lane = lane_id();
+    const int lane = lane_id(), w = wave_id();
     const u64 p0 = bitoff[b];
     const u32 ns = nsel[b];
     const u32 nt = ntables[b];
     const int alpha = (int)alphaArr[b];
-    if (lane == 0) {
+    __shared__ u32 wsum[4];
+    if (threadIdx.x == 0) {
         // S/BZip2BlockCompressor.swift:273-280, :89-144
         u64 p = p0;
         put_bits(out, p, 24, 0x314159); p += 24;
@@ -451,43 +464,47 @@ __global__ __launch_bounds__(64) void k4_write_header(
         put_bits(out, p, 3, nt); p += 3;
         put_bits(out, p, 15, ns); p += 15;
     }
-    // selectors (:304-307): lane chunks, unary codes
+    // selectors (:304-307): thread chunks, unary codes
     {
-        const u32 per = (ns + 63) / 64;
-        const u32 s0 = min(ns, lane * per), s1 = min(ns, s0 + per);
+        const u32 per = (ns + 255) / 256;
+        const u32 s0 = min(ns, threadIdx.x * per), s1 = min(ns, s0 + per);
         const u8 *sp = selpos + (size_t)b * SEL_STRIDE;
         u32 bits = 0;
         for (u32 i = s0; i < s1; i++) bits += sp[i] + 1;
-        u32 inc = wave_incl_scan_add(bits);
-        u64 p = p0 + hdr[b * 4] + (inc - bits);
+        const u32 inc = wave_incl_scan_add(bits);
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        u32 base = 0;
+        for (int q = 0; q < w; q++) base += wsum[q];
+        u64 p = p0 + hdr[b * 4] + base + (inc - bits);
         for (u32 i = s0; i < s1; i++) {
             u32 v = sp[i];
             put_bits(out, p, (int)v + 1, ((1u << v) - 1u) << 1);
             p += v + 1;
         }
     }
-    // tables (:310-327): lane t < nt writes table t serially
-    if ((u32)lane < nt) {
-        // bit offset of table t = sum of previous tables' sizes (recomputed from lengths)
-        const u8 *hl = hlen + ((size_t)b * MAX_TABLES) * HL;
+    // tables (:310-327): start length in 5 bits, then per symbol the steps to its length and a 0
+    for (u32 t = (u32)w; t < nt; t += 4) {
         u64 p = p0 + hdr[b * 4] + hdr[b * 4 + 1];
-        for (int t = 0; t < lane; t++) {
-            const u8 *l = hl + (size_t)t * HL;
-            u32 bits = 5;
-            int cur = l[0];
-            for (int j = 0; j < alpha; j++) {
-                int d = (int)l[j] - cur;
-                bits += 2 * (d < 0 ? -d : d) + 1;
-                cur = l[j];
-            }
-            p += bits;
+        for (u32 q = 0; q < t; q++) p += tblbits[((size_t)b * MAX_TABLES + q) * 2];
+        const u8 *l = hlen + ((size_t)b * MAX_TABLES + t) * HL;
+        const int per = (alpha + 63) / 64;
+        const int j0 = min(alpha, lane * per), j1 = min(alpha, j0 + per);
+        const int before = l[j0 > 0 ? j0 - 1 : 0];
+        u32 bits = 0;
+        int cur = before;
+        for (int j = j0; j < j1; j++) {
+            const int len = l[j];
+            bits += 2u * (u32)(len > cur ? len - cur : cur - len) + 1u;
+            cur = len;
         }
-        const u8 *l = hl + (size_t)lane * HL;
-        int cur = l[0];
-        put_bits(out, p, 5, (u32)cur); p += 5;
-        for (int j = 0; j < alpha; j++) {
-            int len = l[j];
-            u32 v = (cur < len) ? 2u : 3u;
+        const u32 inc = wave_incl_scan_add(bits);
+        if (lane == 0) put_bits(out, p, 5, (u32)l[0]);
+        p += 5 + (inc - bits);
+        cur = before;
+        for (int j = j0; j < j1; j++) {
+            const int len = l[j];
+            const u32 v = (cur < len) ? 2u : 3u;
             int d = len > cur ? len - cur : cur - len;
             while (d-- > 0) { put_bits(out, p, 2, v); p += 2; }
             put_bits(out, p, 1, 0); p += 1;
@@ -748,7 +765,7 @@ void run_pack(bz2hip_ctx *c, int nb, u32 maxmtf, u8 *d_out, u64 first_bit, bool 
         k4_plan<<<nb, 64, 0, c->stream>>>(B.nsel, B.ntables, B.present, B.sel, B.selpos, B.tblbits,
                                           B.hdrbits);
         KCHECK();
-        k4_offsets<<<1, 64, 0, c->stream>>>(B.hdrbits, B.bitoff, nb, first_bit, per_block ? 1 : 0,
+        k4_offsets<<<1, 256, 0, c->stream>>>(B.hdrbits, B.bitoff, nb, first_bit, per_block ? 1 : 0,
                                             (u64)bits_stride * 8);
         KCHECK();
         // exact size check before a single bit is written
@@ -766,9 +783,9 @@ void run_pack(bz2hip_ctx *c, int nb, u32 maxmtf, u8 *d_out, u64 first_bit, bool 
                 throw HipError(BZ2HIP_E_CAP, "output buffer too small");
         }
         if (h_nbits) h_nbits->assign(hb.begin() + nb + 1, hb.begin() + nb + 1 + nb);
-        k4_write_header<<<nb, 64, 0, c->stream>>>(B.nsel, B.ntables, B.alpha, B.present, B.crc,
-                                                  B.orig, B.selpos, B.hlen, B.hdrbits, B.bitoff,
-                                                  (u32 *)d_out);
+        k4_write_header<<<nb, 256, 0, c->stream>>>(B.nsel, B.ntables, B.alpha, B.present, B.crc,
+                                                   B.orig, B.selpos, B.hlen, B.hdrbits, B.tblbits,
+                                                   B.bitoff, (u32 *)d_out);
         KCHECK();
     }
     {
