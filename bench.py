@@ -78,12 +78,10 @@ def main():
     backend = os.environ.get("BZ2_BENCH_BACKEND", "nccl")
     if os.environ.get("BZ2_BENCH_ONE_GPU"):
         local_rank = 0
-    hop_group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-            hop_group = dist.new_group(backend="gloo")  # the block chain: one int64 per hop, host side
         else:
             dist.init_process_group(backend=backend)
     torch.cuda.set_device(local_rank)
@@ -122,15 +120,32 @@ def main():
         n_in = hi - lo
         workload = (f"stream1g generator, ONE stream of {world * seg} MiB sharded over {world} GPUs "
                     f"({seg} MiB per GPU), ordered concatenation on rank 0's GPU")
-        eng = parallel.GpuShardEngine(ctx, local_rank)
-        eng.bind_device(d_slice, lo, end)
+        # Streams back to back through bzip2_amd.parallel.RankPipeline: two engines (contexts)
+        # alternate between consecutive streams; while one compresses stream i, a plan thread runs
+        # the scan and the chain hop of stream i + 1 on the other (the serial hop from rank to rank,
+        # about 1 ms per rank, is hidden behind compression instead of idling every GPU after the
+        # first), and this thread ships stream i - 1's segment to rank 0, which stitches it.  Every
+        # stream is scanned, chained, compressed, gathered and stitched in full inside the timed
+        # region.
+        ctxs = [ctx, Context(device=local_rank, max_batch_blocks=args.batch, profile=0)]
+        engs = [parallel.GpuShardEngine(c, local_rank) for c in ctxs]
+        for e in engs:
+            e.bind_device(d_slice, lo, end)
+            e.compress = e.compress_device
+            e.empty = lambda: (d_none, 0, np.zeros(0, dtype=np.uint32))
+        # gloo groups for the host-side messages, one per thread that uses it
+        hop_group = dist.new_group(backend="gloo")   # the block chain: one int64 per hop (plan thread)
+        meta_group = dist.new_group(backend="gloo")  # segment sizes and block CRCs (this thread)
         cap_seg = L.bz2hip_compress_bound(n_in + look_segs * corpus.MIB)
         seg_words = (cap_seg + 3) // 4 * 4
-        # rank 0: receive buffers for every other rank's segment, and the stream
+        d_none = torch.zeros(8, dtype=torch.uint8, device=dev)
+        # rank 0: receive buffers for every other rank's segment, the stream, and a context of its
+        # own for the stitch (the two above are busy compressing)
         if rank == 0:
             d_recv = [None] + [torch.empty(seg_words + 64, dtype=torch.uint8, device=dev) for _ in range(1, world)]
             cap = L.bz2hip_compress_bound(n_total)
             d_out = torch.empty(cap + 64, dtype=torch.uint8, device=dev)
+            ctx_stitch = Context(device=local_rank, profile=0)
         cpu_comm = backend != "nccl"
         hop_t = torch.zeros(1, dtype=torch.int64)
         MAXCRC = n_in // (level * 50000) + 16
@@ -142,20 +157,26 @@ def main():
         def send_next(v):
             dist.send(torch.tensor([v], dtype=torch.int64), dst=rank + 1, group=hop_group)
 
-        def step():
-            # scan + chain hop + compress (bzip2_amd/parallel.py: run_rank through the C ABI)
-            eng.compress = eng.compress_device
-            eng.empty = lambda: (eng.d_out if eng.d_out is not None else torch.zeros(8, dtype=torch.uint8, device=dev), 0,
-                                 np.zeros(0, dtype=np.uint32))
-            d_seg, nbits, crcs = parallel.run_rank(eng, level, rank, world, n_total, recv_first, send_next,
-                                                   lookahead=end - hi if rank + 1 < world else 0)
+        def plan(eng):
+            return parallel.plan_rank(eng, level, rank, world, n_total, recv_first, send_next,
+                                      lookahead=end - hi if rank + 1 < world else 0)
+
+        def wait_current_stream():
+            # the transfers are ordered on torch's current stream; wait for that stream only (a
+            # device-wide synchronize would also wait for the next stream's compression)
+            ev = torch.cuda.Event()
+            ev.record()
+            ev.synchronize()
+
+        def ship(eng, seg):
+            d_seg, nbits, crcs = seg
             # gather: sizes + CRCs (host, tiny), then the bit segments (device to device)
             meta = torch.zeros(2 + MAXCRC, dtype=torch.int64)
             meta[0] = nbits
             meta[1] = len(crcs)
             meta[2:2 + len(crcs)] = torch.from_numpy(crcs.astype(np.int64))
             metas = [torch.zeros_like(meta) for _ in range(world)] if rank == 0 else None
-            dist.gather(meta, metas, dst=0, group=hop_group)
+            dist.gather(meta, metas, dst=0, group=meta_group)
             nbytes = (nbits + 31) // 32 * 4
             if rank == 0:
                 ops, segs = [], []
@@ -169,7 +190,7 @@ def main():
                     if k:
                         if cpu_comm:
                             buf = torch.empty(k, dtype=torch.uint8)
-                            dist.recv(buf, src=r)
+                            dist.recv(buf, src=r, group=meta_group)
                             d_recv[r][:k].copy_(buf)
                         else:
                             ops.append(dist.P2POp(dist.irecv, d_recv[r][:k], r))
@@ -177,15 +198,24 @@ def main():
                 if ops:
                     for w in dist.batch_isend_irecv(ops):
                         w.wait()
-                torch.cuda.synchronize()
-                return ctx.stitch_device(level, segs, d_out.data_ptr(), cap)
+                wait_current_stream()
+                return ctx_stitch.stitch_device(level, segs, d_out.data_ptr(), cap)
             if nbytes:
                 if cpu_comm:
-                    dist.send(d_seg[:nbytes].cpu(), dst=0)
+                    dist.send(d_seg[:nbytes].cpu(), dst=0, group=meta_group)
                 else:
                     for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, d_seg[:nbytes], 0)]):
                         w.wait()
+                    wait_current_stream()  # the segment has left before its buffer is reused
             return 0
+
+        pipe = parallel.RankPipeline(engs, plan, ship, thread_init=lambda: torch.cuda.set_device(local_rank))
+
+        def run_streams(k):
+            """k streams back to back; returns the last one's length (rank 0).  The plan of the first
+            is requested here, so nothing of a timed stream happens before the clock starts."""
+            res = pipe.run(k)
+            return res[-1] if res else 0
 
     def barrier():
         torch.cuda.synchronize()
@@ -193,15 +223,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        out_len = step()
+    if world == 1:
+        def run_streams(k):
+            out = 0
+            for _ in range(k):
+                out = step()
+            return out
+    out_len = run_streams(args.warmup)
     ctx.profile_reset()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out_len = step()
+    out_len = run_streams(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    if world > 1:
+        pipe.close()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -209,6 +245,8 @@ def main():
 
     stats = ctx.last_stats()
     prof = ctx.profile_get() if not args.no_profile else {}
+    # streams the profiled context handled inside the timed region (N > 1: every second one)
+    prof_steps = args.steps if world == 1 else max(1, sum(1 for j in range(args.warmup, args.warmup + args.steps) if j % 2 == 0))
 
     # correctness guard on rank 0 (outside the timed region)
     check = {}
@@ -284,7 +322,7 @@ def main():
                                "avg_launch_ms": round(avg_ms, 4),
                                "launches": launches, "alg_bytes_per_launch": round(alg)}
             res["kernel_rooflines"] = {
-                KERNEL[k]: {"ms_per_step": round(prof[k]["ms"] / args.steps, 3),
+                KERNEL[k]: {"ms_per_step": round(prof[k]["ms"] / prof_steps, 3),
                             "alg_GBs": round(prof[k]["alg_bytes"] / max(prof[k]["ms"], 1e-9) / 1e6, 1)}
                 for k in KERNEL}
             # elapsed time of the BWT stage in the last step (host clock around its round loop, which
@@ -306,7 +344,7 @@ def main():
                                 "physical_frac": round(phys / t_bwt / 1e9 / HBM_PEAK_GBS, 4) if (phys and t_bwt > 0) else None,
                                 "mean_doubling_rounds": round(stats["rounds_sum"] / max(stats["blocks"], 1), 2),
                                 "periodic_blocks": stats["periodic_blocks"]}
-            res["stage_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in prof.items() if v["launches"]}
+            res["stage_ms_per_step"] = {k: round(v["ms"] / prof_steps, 3) for k, v in prof.items() if v["launches"]}
         if world == 1:
             # the decoder on the stream just written: informational, one pass
             d_back = torch.empty(n_in + 64, dtype=torch.uint8, device=dev)

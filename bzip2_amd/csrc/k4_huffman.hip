@@ -111,17 +111,26 @@ __global__ __launch_bounds__(256) void k4_select(const u16 *__restrict__ mtf,
 
 // ------------------------------------------------------------------ allocator (single lane)
 // S/BZip2HuffmanAllocator.swift:44-66
+// a[i] % len for a parent pointer: the pointers are `tail` or `tail + len` with tail < len, so one
+// conditional subtraction is the remainder (an integer division costs ~40 instructions on a
+// single lane's serial path); the division stays for any other value
+__device__ __forceinline__ int ha_mod(int x, int len) {
+    if ((unsigned)x < (unsigned)len) return x;
+    if ((unsigned)x < 2u * (unsigned)len) return x - len;
+    return x % len;
+}
+
 __device__ int ha_first(const int *a, int len, int i, int nodes_to_move) {
     int limit = i;
     int k = len - 2;
-    while (i >= nodes_to_move && (a[i] % len) > limit) {
+    while (i >= nodes_to_move && ha_mod(a[i], len) > limit) {
         k = i;
         i -= (limit - i + 1);
     }
     i = max(nodes_to_move - 1, i);
     while (k > i + 1) {
         int temp = (i + k) >> 1;
-        if ((a[temp] % len) > limit) k = temp; else i = temp;
+        if (ha_mod(a[temp], len) > limit) k = temp; else i = temp;
     }
     return k;
 }
@@ -148,7 +157,7 @@ __device__ void ha_allocate(int *a, int len, int max_len) {
         for (int depth = 1; depth < max_len - 1 && node > 1; depth++) node = ha_first(a, len, node - 1, 0);
         r = node;
     }
-    if ((a[0] % len) >= r) {
+    if (ha_mod(a[0], len) >= r) {
         int first_node = len - 2, next_node = len - 1;
         for (int depth = 1, avail = 2; avail > 0; depth++) {
             int last_node = first_node;

@@ -17,6 +17,9 @@ The output is byte-identical for every world size.
 `engine` abstracts the compute: on a GPU it is GpuShardEngine (the C ABI); CPU tests inject a
 stand-in so that the chain hopping, the lookahead logic and the stitch run under gloo.
 """
+import queue
+import threading
+
 import numpy as np
 
 from ._lib import stitch
@@ -45,11 +48,13 @@ def max_lookahead(level):
     return level * 100000 * 52 + 65536
 
 
-def run_rank(engine, level, rank, world, n_total, recv_first=None, send_next=None, lookahead=None):
-    """One rank's part of the stream.  engine.load(lo, end) makes the bytes [lo, end) of the stream
-    resident and scans them; engine.chain(first_rel, limit_rel, final) -> (n_blocks, next_rel);
-    engine.compress() -> segment (bits, nbits, crcs).  recv_first() / send_next(v) carry the block
-    chain between neighbouring ranks.  Returns the rank's segment."""
+def plan_rank(engine, level, rank, world, n_total, recv_first=None, send_next=None, lookahead=None):
+    """Steps 1 and 2 of one rank's part: scan, then the rank's stretch of the block chain.
+    engine.load(lo, end) makes the bytes [lo, end) of the stream resident and scans them;
+    engine.chain(first_rel, limit_rel, final) -> (n_blocks, next_rel); recv_first() / send_next(v)
+    carry the block chain between neighbouring ranks.  Returns the number of blocks that start in
+    this rank's range.  Nothing here depends on the compression of any block, so a caller with a
+    second engine can plan the next stream while this one is still being compressed (bench.py)."""
     if not 1 <= level <= 9:
         raise ValueError(f"Invalid BZip2 block size {level}")
     lo, hi = nominal_ranges(n_total, world)[rank]
@@ -75,9 +80,96 @@ def run_rank(engine, level, rank, world, n_total, recv_first=None, send_next=Non
         look = min(look * 4, max_lookahead(level))  # the last block ran into the end of the slice
     if rank + 1 < world and send_next is not None:
         send_next(nxt)
+    return nblocks
+
+
+def run_rank(engine, level, rank, world, n_total, recv_first=None, send_next=None, lookahead=None):
+    """One rank's part of the stream: plan_rank, then engine.compress() -> the rank's segment
+    (bits, nbits, crcs)."""
+    nblocks = plan_rank(engine, level, rank, world, n_total, recv_first, send_next, lookahead)
     if nblocks == 0:
         return engine.empty()
     return engine.compress()
+
+
+class RankPipeline:
+    """Streams back to back on one rank, as three overlapping stages on alternating engines:
+      plan     (thread)  scan + this rank's stretch of the block chain      -- plan(engine) -> n_blocks
+      compress (thread)  engine.compress() -> segment
+      ship     (caller)  hand the segment on (gather, stitch)               -- ship(engine, segment)
+    While engine j % E compresses stream j, the plan of stream j + 1 runs on the next engine, so the
+    serial hop of the chain from rank to rank is hidden behind compression instead of idling every
+    GPU after the first; the segment of stream j is shipped while stream j + 1 is compressed.  An
+    engine's segment buffer is not reused before its last segment has been shipped.  Each stage is
+    used by one thread only (give each its own communicator: the plan stage the hop, the caller
+    the gather).  run(k) does all the work of its k streams between its call and its return."""
+
+    def __init__(self, engines, plan, ship, thread_init=None):
+        self.engines = list(engines)
+        self.plan, self.ship, self.thread_init = plan, ship, thread_init
+        self.n = 0  # number of the next stream
+        self._end = 0
+        self._q_plan, self._q_planned, self._q_done = queue.Queue(), queue.Queue(), queue.Queue()
+        self._shipped = [threading.Semaphore(1) for _ in self.engines]
+        self._threads = [threading.Thread(target=self._planner, daemon=True),
+                         threading.Thread(target=self._compressor, daemon=True)]
+        for t in self._threads:
+            t.start()
+
+    def _planner(self):
+        if self.thread_init:
+            self.thread_init()
+        while True:
+            j = self._q_plan.get()
+            if j is None:
+                self._q_planned.put(None)
+                return
+            try:
+                self._q_planned.put((j, self.plan(self.engines[j % len(self.engines)]), None))
+            except BaseException as ex:  # raised again by run()
+                self._q_planned.put((j, 0, ex))
+
+    def _compressor(self):
+        if self.thread_init:
+            self.thread_init()
+        while True:
+            item = self._q_planned.get()
+            if item is None:
+                return
+            j, nblocks, ex = item
+            seg = None
+            if ex is None:
+                try:
+                    e = j % len(self.engines)
+                    self._shipped[e].acquire()  # this engine's previous segment has left its buffer
+                    if j + 1 < self._end:
+                        self._q_plan.put(j + 1)
+                    seg = self.engines[e].compress() if nblocks else self.engines[e].empty()
+                except BaseException as ex2:
+                    ex = ex2
+            self._q_done.put((j, seg, ex))
+
+    def run(self, k):
+        """k streams; returns ship()'s results in stream order."""
+        results = []
+        if k <= 0:
+            return results
+        self._end = self.n + k
+        self._q_plan.put(self.n)
+        for _ in range(k):
+            j, seg, ex = self._q_done.get()
+            if ex is not None:
+                raise ex
+            e = j % len(self.engines)
+            results.append(self.ship(self.engines[e], seg))
+            self._shipped[e].release()
+            self.n = j + 1
+        return results
+
+    def close(self):
+        self._q_plan.put(None)
+        for t in self._threads:
+            t.join(timeout=30)
 
 
 def compress_sharded(data, level, engine, rank=0, world=1, gather=None, recv_first=None,

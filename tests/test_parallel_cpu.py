@@ -107,6 +107,66 @@ def test_sharded_stream_gloo_world2():
     assert loads > 1  # rank 0's last block ran past its lookahead: the slice was extended
 
 
+def _pipe_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orc
+    from bzip2_amd import corpus, parallel
+    from bzip2_amd._lib import stitch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    hop_group = dist.new_group(backend="gloo")  # used by the plan thread only
+    datas = [corpus.mixed(3, 77, seg_bytes=190000), np.concatenate((corpus.text(250000, 9), np.zeros(300000, dtype=np.uint8)))]
+    level = 1
+    engines = []
+    for d in datas:
+        e = OracleEngine(orc)
+        e.bind(d)
+        engines.append(e)
+
+    def recv_first():
+        t = torch.zeros(1, dtype=torch.int64)
+        dist.recv(t, src=rank - 1, group=hop_group)
+        return int(t.item())
+
+    def send_next(v):
+        dist.send(torch.tensor([v], dtype=torch.int64), dst=rank + 1, group=hop_group)
+
+    def plan(eng):
+        return parallel.plan_rank(eng, level, rank, world, eng.a.size, recv_first, send_next, lookahead=40000)
+
+    def ship(eng, seg):
+        out = [None] * world if rank == 0 else None
+        dist.gather_object((np.asarray(seg[0]), int(seg[1]), np.asarray(seg[2], dtype=np.uint32)), out, dst=0)
+        return stitch(level, out) if rank == 0 else None
+
+    pipe = parallel.RankPipeline(engines, plan, ship)
+    res = pipe.run(3) + pipe.run(2)  # two regions: the stream counter runs on
+    pipe.close()
+    if rank == 0:
+        refs = [orc.compress(d, level)[0] for d in datas]
+        q.put([res[j] == refs[j % 2] for j in range(5)])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rank_pipeline_gloo_world2():
+    """plan / compress / ship overlapped over consecutive streams on alternating engines: every
+    stream comes out as the oracle's, in order."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_pipe_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    oks = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert oks == [True] * 5
+
+
 @pytest.mark.parametrize("world", [1, 2, 3, 5, 8])
 def test_chain_hopping_sequential(orc, world):
     """All ranks in one process, in rank order (the hop is a variable): every world size gives the
