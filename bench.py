@@ -63,6 +63,12 @@ def main():
     ap.add_argument("--profile-all", action="store_true",
                     help="HIP events around every kernel class (adds ~2 ms per step of event overhead)")
     args = ap.parse_args()
+    # stdout carries the ONE JSON line and nothing else: libraries write there too (gloo prints its
+    # connection notices on stdout), so file descriptor 1 is pointed at stderr and the JSON line is
+    # written to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -396,7 +402,8 @@ def main():
                                    "all_cores": {"value": round(sample.size / tm / 1e6, 2),
                                                  "cores": cores},
                                    "gpu_output_equals_oracle": same}
-        print(json.dumps(res), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
     ctx.close()
     if world > 1:
         dist.barrier()

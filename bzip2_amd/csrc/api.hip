@@ -455,7 +455,7 @@ static void compress_window_blocks(bz2hip_ctx *c, const u8 *d_win, const std::ve
         const int nb = (int)std::min<u32>(bsz, usable - b0);
         u32 max_in = 0;
         for (int b = 0; b < nb; b++) max_in = std::max(max_in, starts[b0 + b + 1] - starts[b0 + b]);
-        run_rle1_emit(c, d_win, c->w_rs, c->w_starts, b0, nb, max_in, c->w_eagg, c->w_ETPB);
+        run_rle1_emit(c, d_win, c->w_agg1, c->w_starts, b0, nb, max_in, c->w_eagg, c->w_ETPB);
         run_bwt_n(c, nb, bs);
         run_mtf(c, nb, bs);
         run_huffman(c, nb, bs + 1);
@@ -1484,7 +1484,7 @@ extern "C" int bz2hip_rle1_split(bz2hip_ctx *c, const uint8_t *in, size_t n, int
                     int nb = (int)std::min<u32>((u32)B.NB, usable - b0);
                     u32 max_in = 0;
                     for (int b = 0; b < nb; b++) max_in = std::max(max_in, hs[b0 + b + 1] - hs[b0 + b]);
-                    run_rle1_emit(c, c->h_in, c->w_rs, c->w_starts, b0, nb, max_in, c->w_eagg, c->w_ETPB);
+                    run_rle1_emit(c, c->h_in, c->w_agg1, c->w_starts, b0, nb, max_in, c->w_eagg, c->w_ETPB);
                     HIPCHK(hipStreamSynchronize(c->stream));
                     const size_t o = (size_t)total + b0;
                     HIPCHK(hipMemcpy2D(rle + o * rstride, rstride, B.T, B.S, bs, nb, hipMemcpyDeviceToHost));

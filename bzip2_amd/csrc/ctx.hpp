@@ -299,5 +299,5 @@ u32 run_chain(bz2hip_ctx *c, u32 n, int level, const u32 *d_rs, const u32 *d_P, 
               u32 *d_starts, u32 max_blocks, u32 s0, u32 stop, std::vector<u32> &h_starts);
 u32 run_split(bz2hip_ctx *c, const u8 *d_in, u32 n, int level, u32 *d_rs, u32 *d_P, u32 *d_agg1,
               u32 *d_agg2, u32 *d_starts, u32 max_blocks, std::vector<u32> &h_starts);
-void run_rle1_emit(bz2hip_ctx *c, const u8 *d_in, const u32 *d_rs, const u32 *d_starts, u32 b0,
+void run_rle1_emit(bz2hip_ctx *c, const u8 *d_in, const u32 *d_agg_head, const u32 *d_starts, u32 b0,
                    int nb, u32 max_in_len, u32 *d_eagg, u32 ETPB);

@@ -331,61 +331,102 @@ __global__ __launch_bounds__(64) void k1_split(const u32 *__restrict__ rs,
 }
 
 // ---------------------------------------------------------------- per-block RLE1 emit
-// element j of block b = input position starts[b0+b] + j.  3-phase scan of emitted bytes.
-__device__ __forceinline__ u32 emit_count(const u8 *__restrict__ in, const u32 *__restrict__ rs,
-                                          u32 s, u32 e, u32 i, u32 *count_byte, bool *has_count) {
-    u32 r0 = rs[i];
-    if (r0 < s) r0 = s;
-    u32 k = (i - r0) % 255u;
-    bool chunk_end = (k == 254u) || (i + 1 == e) || (in[i + 1] != in[i]);
-    bool hc = chunk_end && k >= 3u;
-    *has_count = hc;
-    *count_byte = k - 3u;
-    return (k < 4u ? 1u : 0u) + (hc ? 1u : 0u);
-}
+// Tile x of block b is the global tile (starts[b] / K1_TILE + x) cut to [s, e): the tiles of the
+// scan and of the emit coincide, so a tile's run starts follow from its own bytes and the scan's
+// "last head before this tile" (agg_head) -- no per-byte array is read.  The block start is a
+// forced head (a run that straddles s is cut there, S/BZip2BlockCompressor.swift:198-227).
+// 3-phase scan of emitted bytes.  Every thread owns 16 consecutive bytes (one 16-byte load) and
+// walks them serially with the run start in a register; the run start that enters a thread comes
+// from a max-scan of "last head" over the threads before it.
+struct EmitLane {
+    u32 w[4];      // the 16 bytes
+    u32 heads;     // bit j: byte j starts a run (inside [s, e))
+    u32 nxt;       // the byte after the 16
+    u32 r0;        // start of the run that enters byte 0 (>= s)
+};
 
-// same with the three inputs already loaded (r0 = rs[i], cur = in[i], nxt = in[i + 1])
-__device__ __forceinline__ u32 emit_count_v(u32 r0, u8 cur, u8 nxt, u32 s, u32 e, u32 i,
-                                            u32 *count_byte, bool *has_count) {
-    if (r0 < s) r0 = s;
-    u32 k = (i - r0) % 255u;
-    bool chunk_end = (k == 254u) || (i + 1 == e) || (nxt != cur);
-    bool hc = chunk_end && k >= 3u;
-    *has_count = hc;
-    *count_byte = k - 3u;
-    return (k < 4u ? 1u : 0u) + (hc ? 1u : 0u);
+// loads and head detection; returns the thread's emitted-byte count
+__device__ __forceinline__ u32 emit_lane(const u8 *__restrict__ in, const u32 *__restrict__ agg_head,
+                                         u32 s, u32 e, u32 gt, u32 *sm /* 8 words */, EmitLane &L) {
+    const int lane = lane_id(), wv = wave_id();
+    const u32 pos = gt * K1_TILE + threadIdx.x * 16u;
+    // the 16 bytes: one aligned 16-byte load when they all lie below e (bytes before s belong to
+    // the window too), single bytes at the block's end and for an unaligned input
+    if (pos + 16u <= e && (((uintptr_t)(in + pos)) & 15u) == 0) {
+        const uint4 v = *(const uint4 *)(in + pos);
+        L.w[0] = v.x; L.w[1] = v.y; L.w[2] = v.z; L.w[3] = v.w;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            u32 x = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const u32 i = pos + q * 4 + j;
+                if (i < e) x |= (u32)in[i] << (8 * j);
+            }
+            L.w[q] = x;
+        }
+    }
+    // neighbours: last byte of the thread before, first byte of the thread after
+    u32 prv = __shfl_up(L.w[3] >> 24, 1, 64);
+    u32 nxt = __shfl_down(L.w[0] & 255u, 1, 64);
+    if (lane == 0 && pos > s && pos < e) prv = in[pos - 1];
+    if (lane == 63 && pos + 16u < e) nxt = in[pos + 16u];
+    L.nxt = nxt;
+    u32 heads = 0, lastp1 = 0;
+    u32 pb = prv;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const u32 i = pos + j;
+        const u32 c = (L.w[j >> 2] >> (8 * (j & 3))) & 255u;
+        const bool h = i >= s && i < e && (i == s || c != pb);
+        if (h) {
+            heads |= 1u << j;
+            lastp1 = i + 1;
+        }
+        pb = c;
+    }
+    L.heads = heads;
+    // last head (+1) before this thread: the tile's carry, the block start, the threads before
+    const u32 inc = wave_incl_scan_max(lastp1);
+    if (lane == 63) sm[wv] = inc;
+    __syncthreads();
+    u32 carry = max(agg_head[gt], s + 1u);
+    for (int q = 0; q < wv; q++) carry = max(carry, sm[q]);
+    const u32 up = __shfl_up(inc, 1, 64);
+    if (lane > 0) carry = max(carry, up);
+    L.r0 = carry - 1u;
+    // count
+    u32 r0 = L.r0, tot = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const u32 i = pos + j;
+        if ((heads >> j) & 1u) r0 = i;
+        if (i >= s && i < e) {
+            u32 k = i - r0;
+            if (k >= 255u) k %= 255u;
+            const u32 c = (L.w[j >> 2] >> (8 * (j & 3))) & 255u;
+            const u32 cn = j < 15 ? ((L.w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 255u) : nxt;
+            const bool chunk_end = (k == 254u) || (i + 1 == e) || (cn != c);
+            tot += (k < 4u ? 1u : 0u) + ((chunk_end && k >= 3u) ? 1u : 0u);
+        }
+    }
+    return tot;
 }
 
 __global__ __launch_bounds__(256) void k1_emit_p1(const u8 *__restrict__ in,
-                                                  const u32 *__restrict__ rs,
+                                                  const u32 *__restrict__ agg_head,
                                                   const u32 *__restrict__ starts,
                                                   u32 *__restrict__ eagg, u32 ETPB) {
     const u32 b = blockIdx.y;
     const u32 s = starts[b], e = starts[b + 1];
-    const u32 base = s + blockIdx.x * K1_TILE;
-    if (base >= e) return;
+    const u32 gt = s / K1_TILE + blockIdx.x;
+    if (gt * K1_TILE >= e) return;
     __shared__ u32 sm[8];
-    u32 tot = 0;
-    u32 rv[16];
-    u8 cur[16], nxt[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const u32 i = base + k * 256 + threadIdx.x;
-        const u32 ic = i < e ? i : e - 1;
-        rv[k] = rs[ic];
-        cur[k] = in[ic];
-        nxt[k] = in[ic + 1 < e ? ic + 1 : e - 1];
-    }
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        u32 i = base + k * 256 + threadIdx.x;
-        if (i < e) {
-            u32 cb;
-            bool hc;
-            tot += emit_count_v(rv[k], cur[k], nxt[k], s, e, i, &cb, &hc);
-        }
-    }
-    u32 t = block_reduce_add<256>(tot, sm);
+    __shared__ u32 red[8];
+    EmitLane L;
+    const u32 tot = emit_lane(in, agg_head, s, e, gt, sm, L);
+    const u32 t = block_reduce_add<256>(tot, red);
     if (threadIdx.x == 0) eagg[(size_t)b * ETPB + blockIdx.x] = t;
 }
 
@@ -393,8 +434,9 @@ __global__ __launch_bounds__(256) void k1_emit_p2(const u32 *__restrict__ starts
                                                   u32 *__restrict__ eagg, u32 *__restrict__ nOut,
                                                   u32 *__restrict__ present, u32 ETPB) {
     const u32 b = blockIdx.x;
-    const u32 len = starts[b + 1] - starts[b];
-    const u32 tiles = (len + K1_TILE - 1) / K1_TILE;
+    // global tiles the block touches
+    const u32 sb = starts[b], eb = starts[b + 1];
+    const u32 tiles = eb > sb ? (eb - 1) / K1_TILE - sb / K1_TILE + 1 : 0;
     __shared__ u32 sm[8];
     u32 carry = 0;
     for (u32 t0 = 0; t0 < tiles; t0 += 256) {
@@ -410,68 +452,52 @@ __global__ __launch_bounds__(256) void k1_emit_p2(const u32 *__restrict__ starts
     if (threadIdx.x < 8) present[b * 8 + threadIdx.x] = 0;
 }
 
+#define K1_EMIT_STAGE (K1_TILE + K1_TILE / 4 + 64) // a run of 4 emits 5 bytes: at most 1.25 per input byte
 __global__ __launch_bounds__(256) void k1_emit_p3(const u8 *__restrict__ in,
-                                                  const u32 *__restrict__ rs,
+                                                  const u32 *__restrict__ agg_head,
                                                   const u32 *__restrict__ starts,
                                                   const u32 *__restrict__ eagg, u8 *__restrict__ T,
                                                   u32 *__restrict__ present, u32 S, u32 ETPB) {
     const u32 b = blockIdx.y;
     const u32 s = starts[b], e = starts[b + 1];
-    const u32 base = s + blockIdx.x * K1_TILE;
-    if (base >= e) return;
-    const int w = wave_id(), lane = lane_id();
-    __shared__ u32 wsum[4];
+    const u32 gt = s / K1_TILE + blockIdx.x;
+    if (gt * K1_TILE >= e) return;
+    __shared__ u32 sm[8];
+    __shared__ u32 red[8];
     __shared__ u32 pres[8];
+    __shared__ u8 stage[K1_EMIT_STAGE];
     if (threadIdx.x < 8) pres[threadIdx.x] = 0;
-    u32 ec[16], cbv[16];
-    u32 wtot = 0;
-    u32 rv[16];
-    u8 cur[16], nxt[16];
+    EmitLane L;
+    const u32 tot = emit_lane(in, agg_head, s, e, gt, sm, L);
+    u32 total;
+    u32 o = block_excl_scan_add<256>(tot, red, &total); // has a barrier after pres is cleared
+    // the thread's bytes into the staging tile (a value enters the bitmap once per run)
+    const u32 pos = gt * K1_TILE + threadIdx.x * 16u;
+    u32 r0 = L.r0;
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const u32 i = base + w * 1024 + k * 64 + lane;
-        const u32 ic = i < e ? i : e - 1;
-        rv[k] = rs[ic];
-        cur[k] = in[ic];
-        nxt[k] = in[ic + 1 < e ? ic + 1 : e - 1];
-    }
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        u32 i = base + w * 1024 + k * 64 + lane;
-        u32 c = 0, cb = 0;
-        bool hc = false;
-        if (i < e) c = emit_count_v(rv[k], cur[k], nxt[k], s, e, i, &cb, &hc);
-        ec[k] = c;
-        cbv[k] = hc ? cb : 0xffffffffu;
-        wtot += c;
-    }
-    wtot = wave_reduce_add(wtot);
-    if (lane == 0) wsum[w] = wtot;
-    __syncthreads();
-    u32 run = eagg[(size_t)b * ETPB + blockIdx.x];
-    for (int q = 0; q < w; q++) run += wsum[q];
-    u8 *out = T + (size_t)b * S;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        u32 c = ec[k];
-        u32 inc = wave_incl_scan_add(c);
-        u32 o = run + inc - c;
-        run += __shfl(inc, 63, 64);
-        if (c) {
-            u8 v = cur[k];
-            bool hc = cbv[k] != 0xffffffffu;
-            if (c == 2 || !hc) { // the data byte itself is emitted
-                out[o++] = v;
-                atomicOr(&pres[v >> 5], 1u << (v & 31));
+    for (int j = 0; j < 16; j++) {
+        const u32 i = pos + j;
+        if ((L.heads >> j) & 1u) r0 = i;
+        if (i >= s && i < e) {
+            u32 k = i - r0;
+            if (k >= 255u) k %= 255u;
+            const u32 c = (L.w[j >> 2] >> (8 * (j & 3))) & 255u;
+            const u32 cn = j < 15 ? ((L.w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 255u) : L.nxt;
+            const bool chunk_end = (k == 254u) || (i + 1 == e) || (cn != c);
+            if (k < 4u) {
+                stage[o++] = (u8)c;
+                if (k == 0u) atomicOr(&pres[c >> 5], 1u << (c & 31));
             }
-            if (hc) {
-                u32 cb = cbv[k];
-                out[o] = (u8)cb;
+            if (chunk_end && k >= 3u) {
+                const u32 cb = k - 3u;
+                stage[o++] = (u8)cb;
                 atomicOr(&pres[cb >> 5], 1u << (cb & 31));
             }
         }
     }
     __syncthreads();
+    u8 *out = T + (size_t)b * S + eagg[(size_t)b * ETPB + blockIdx.x];
+    for (u32 q = threadIdx.x; q < total; q += 256) out[q] = stage[q];
     if (threadIdx.x < 8 && pres[threadIdx.x]) atomicOr(&present[b * 8 + threadIdx.x], pres[threadIdx.x]);
 }
 
@@ -679,11 +705,13 @@ void run_crc_blocks(bz2hip_ctx *c, const u8 *d_data, const u32 *d_starts, int nb
 }
 
 // RLE1-encode blocks [b0, b0+nb) of the window into the batch; CRC per block.
-void run_rle1_emit(bz2hip_ctx *c, const u8 *d_in, const u32 *d_rs, const u32 *d_starts, u32 b0,
+void run_rle1_emit(bz2hip_ctx *c, const u8 *d_in, const u32 *d_agg_head, const u32 *d_starts, u32 b0,
                    int nb, u32 max_in_len, u32 *d_eagg, u32 ETPB) {
     Batch &B = c->batch;
     const u32 tiles = (max_in_len + K1_TILE - 1) / K1_TILE;
     dim3 grid(tiles, nb);
+    // the emit tiles are the scan's global tiles: a block of `len` bytes touches up to one more
+    dim3 egrid(std::min(tiles + 1, ETPB), nb);
     // The block CRCs depend only on the input and the block starts: they run on the other stream,
     // next to the emit scan; this stream waits for them before anything that follows.
     {
@@ -695,11 +723,11 @@ void run_rle1_emit(bz2hip_ctx *c, const u8 *d_in, const u32 *d_rs, const u32 *d_
     }
     {
         ProfScope ps(c, P_RLE1_EMIT, 0);
-        k1_emit_p1<<<grid, 256, 0, c->stream>>>(d_in, d_rs, d_starts + b0, d_eagg, ETPB);
+        k1_emit_p1<<<egrid, 256, 0, c->stream>>>(d_in, d_agg_head, d_starts + b0, d_eagg, ETPB);
         KCHECK();
         k1_emit_p2<<<nb, 256, 0, c->stream>>>(d_starts + b0, d_eagg, B.n, B.present, ETPB);
         KCHECK();
-        k1_emit_p3<<<grid, 256, 0, c->stream>>>(d_in, d_rs, d_starts + b0, d_eagg, B.T, B.present,
+        k1_emit_p3<<<egrid, 256, 0, c->stream>>>(d_in, d_agg_head, d_starts + b0, d_eagg, B.T, B.present,
                                                 B.S, ETPB);
         KCHECK();
     }
