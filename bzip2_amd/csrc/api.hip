@@ -125,6 +125,7 @@ static void wfree(bz2hip_ctx *c) {
     if (c->w_eregion) (void)hipFree(c->w_eregion);
     c->w_region = c->w_eregion = nullptr;
     c->w_rs = c->w_P = c->w_agg1 = c->w_agg2 = c->w_starts = c->w_eagg = c->w_cagg = nullptr;
+    c->w_P16 = nullptr;
 }
 
 static u32 window_max_blocks(size_t wlen, int level) {
@@ -135,13 +136,17 @@ static u32 emit_tiles_per_block(int level) {
     return (u32)(((u64)level * 100000u * 52 + 2048) / 4096 + 2);
 }
 
-// window scratch: rs, P (u32 per input byte), tile aggregates, block starts
+// window scratch: the cell records (last head before / flushed-length prefix at every 256th input
+// byte; w_rs = Hc, w_P = Pc of k1_rle1.hip), the 16-bit tile-local prefix per input byte, tile
+// aggregates, block starts
 static size_t layout_window(bz2hip_ctx *c, size_t wlen, u32 mb, u8 *base) {
     Carver A{base};
     const size_t tiles = (wlen + 4095) / 4096 + 2;
-    u32 *rs = A.get<u32>(wlen + 16), *P = A.get<u32>(wlen + 16);
+    const size_t cells = wlen / 256 + 4;
+    u32 *rs = A.get<u32>(cells), *P = A.get<u32>(cells);
+    u16 *p16 = A.get<u16>(wlen + 16);
     u32 *a1 = A.get<u32>(tiles), *a2 = A.get<u32>(tiles), *st = A.get<u32>((size_t)mb + 8);
-    if (base) { c->w_rs = rs; c->w_P = P; c->w_agg1 = a1; c->w_agg2 = a2; c->w_starts = st; }
+    if (base) { c->w_rs = rs; c->w_P = P; c->w_P16 = p16; c->w_agg1 = a1; c->w_agg2 = a2; c->w_starts = st; }
     return A.off;
 }
 // per-batch emit / CRC tile partials
@@ -487,8 +492,8 @@ static size_t compress_core(bz2hip_ctx *c, const u8 *d_in, size_t n, int level, 
         const size_t wlen = std::min<size_t>(n - pos, WMAX);
         const bool last_window = (pos + wlen == n);
         const bool two = prepare_window(c, d_in + pos, wlen, level);
-        u32 cnt = run_chain(c, (u32)wlen, level, c->w_rs, c->w_P, c->w_agg2, c->w_starts, c->w_maxblocks, 0,
-                            (u32)wlen, starts);
+        u32 cnt = run_chain(c, d_in + pos, (u32)wlen, level, c->w_rs, c->w_P, c->w_agg2, c->w_starts,
+                            c->w_maxblocks, 0, (u32)wlen, starts);
         // a block that ends at the window end is complete only if this is the final data
         u32 usable = cnt;
         if (!(last_window && final) && cnt > 0 && starts[cnt] == (u32)wlen) usable = cnt - 1;
@@ -562,6 +567,7 @@ extern "C" int bz2hip_compress_device_noalloc(bz2hip_ctx *c, const void *d_in, s
             bz2hip_ctx *c;
             Batch batch;
             u32 *w_rs, *w_P, *w_agg1, *w_agg2, *w_starts, *w_eagg, *w_cagg;
+            u16 *w_P16;
             size_t w_cap;
             u32 w_maxblocks, w_ETPB;
             int w_eagg_nb;
@@ -569,7 +575,7 @@ extern "C" int bz2hip_compress_device_noalloc(bz2hip_ctx *c, const void *d_in, s
             explicit Saved(bz2hip_ctx *cc)
                 : c(cc), batch(std::move(cc->batch)), w_rs(cc->w_rs), w_P(cc->w_P), w_agg1(cc->w_agg1),
                   w_agg2(cc->w_agg2), w_starts(cc->w_starts), w_eagg(cc->w_eagg), w_cagg(cc->w_cagg),
-                  w_cap(cc->w_cap), w_maxblocks(cc->w_maxblocks), w_ETPB(cc->w_ETPB),
+                  w_P16(cc->w_P16), w_cap(cc->w_cap), w_maxblocks(cc->w_maxblocks), w_ETPB(cc->w_ETPB),
                   w_eagg_nb(cc->w_eagg_nb), profile(cc->profile) {
                 cc->batch = Batch();
                 cc->fixed_ws = true;
@@ -579,6 +585,7 @@ extern "C" int bz2hip_compress_device_noalloc(bz2hip_ctx *c, const void *d_in, s
                 c->batch = std::move(batch);
                 c->w_rs = w_rs; c->w_P = w_P; c->w_agg1 = w_agg1; c->w_agg2 = w_agg2;
                 c->w_starts = w_starts; c->w_eagg = w_eagg; c->w_cagg = w_cagg;
+                c->w_P16 = w_P16;
                 c->w_cap = w_cap; c->w_maxblocks = w_maxblocks; c->w_ETPB = w_ETPB;
                 c->w_eagg_nb = w_eagg_nb;
                 c->profile = profile;
@@ -649,8 +656,8 @@ extern "C" int bz2hip_shard_chain(bz2hip_ctx *c, uint64_t first, uint64_t limit,
         *next = first;
         c->sh_state = 2;
         if (first >= limit) return BZ2HIP_OK; // the previous shard's last block swallowed this one
-        u32 cnt = run_chain(c, (u32)c->sh_avail, c->sh_level, c->w_rs, c->w_P, c->w_agg2, c->w_starts,
-                            c->w_maxblocks, (u32)first, (u32)limit, c->sh_starts);
+        u32 cnt = run_chain(c, c->sh_in, (u32)c->sh_avail, c->sh_level, c->w_rs, c->w_P, c->w_agg2,
+                            c->w_starts, c->w_maxblocks, (u32)first, (u32)limit, c->sh_starts);
         // a block that runs into the end of the data is complete only if the stream ends there
         u32 usable = cnt;
         if (!final && cnt > 0 && c->sh_starts[cnt] == (u32)c->sh_avail) usable = cnt - 1;
@@ -1471,8 +1478,8 @@ extern "C" int bz2hip_rle1_split(bz2hip_ctx *c, const uint8_t *in, size_t n, int
             ensure_staging(c, wlen, 0);
             HIPCHK(hipMemcpyAsync(c->h_in, in + pos, wlen, hipMemcpyHostToDevice, c->stream));
             prepare_window(c, c->h_in, wlen, level);
-            u32 cnt = run_chain(c, (u32)wlen, level, c->w_rs, c->w_P, c->w_agg2, c->w_starts, c->w_maxblocks, 0,
-                                (u32)wlen, hs);
+            u32 cnt = run_chain(c, c->h_in, (u32)wlen, level, c->w_rs, c->w_P, c->w_agg2, c->w_starts,
+                                c->w_maxblocks, 0, (u32)wlen, hs);
             u32 usable = cnt;
             if (!last_window && cnt > 0 && hs[cnt] == (u32)wlen) usable = cnt - 1;
             if (usable == 0) throw HipError(BZ2HIP_E_HIP, "window holds no complete block");

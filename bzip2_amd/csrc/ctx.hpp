@@ -141,6 +141,7 @@ struct bz2hip_ctx {
     // window scratch for K1 (split / RLE1 / CRC)
     u32 *w_rs = nullptr, *w_P = nullptr, *w_agg1 = nullptr, *w_agg2 = nullptr;
     u32 *w_starts = nullptr, *w_eagg = nullptr;
+    u16 *w_P16 = nullptr;    // flushed-length prefix per input byte, tile-local (k1_rle1.hip)
     u32 *w_cagg = nullptr;   // CRC tile partials (same shape as w_eagg; used on the other stream)
     void *w_region = nullptr;  // device region holding rs / P / aggregates / starts
     void *w_eregion = nullptr; // device region holding the emit / CRC tile partials
@@ -295,7 +296,7 @@ void run_frame(bz2hip_ctx *c, int nb, u8 *d_out, int level, bool header, bool tr
 // K1 (k1_rle1.hip)
 void k1_init_tables(bz2hip_ctx *c);
 void run_scan(bz2hip_ctx *c, const u8 *d_in, u32 n, u32 *d_rs, u32 *d_P, u32 *d_agg1, u32 *d_agg2);
-u32 run_chain(bz2hip_ctx *c, u32 n, int level, const u32 *d_rs, const u32 *d_P, const u32 *d_agg2,
+u32 run_chain(bz2hip_ctx *c, const u8 *d_in, u32 n, int level, const u32 *d_rs, const u32 *d_P, const u32 *d_agg2,
               u32 *d_starts, u32 max_blocks, u32 s0, u32 stop, std::vector<u32> &h_starts);
 u32 run_split(bz2hip_ctx *c, const u8 *d_in, u32 n, int level, u32 *d_rs, u32 *d_P, u32 *d_agg1,
               u32 *d_agg2, u32 *d_starts, u32 max_blocks, std::vector<u32> &h_starts);

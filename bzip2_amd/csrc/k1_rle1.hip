@@ -82,14 +82,19 @@ __global__ __launch_bounds__(1024) void k1_scan_tiles(u32 *__restrict__ agg, u32
     if (threadIdx.x == 0 && total_out) *total_out = carry;
 }
 
-// per-row helper: run start of every element of the tile, wave-row layout
-// phase 3: rs[i] and tile sums of c(i)
-// P is stored tile-local (exclusive prefix of c inside the tile); readers add the scanned tile
-// sums (agg_c) -> one pass over the input instead of two.
-__global__ __launch_bounds__(256) void k1_runs(const u8 *__restrict__ in, u32 n,
-                                               const u32 *__restrict__ agg_head,
-                                               u32 *__restrict__ rs, u32 *__restrict__ agg_c,
-                                               u32 *__restrict__ P, u32 tile0) {
+// The flushed-length prefix P and the run starts are kept per CELL of 256 input bytes, not per
+// byte: Hc[c] = last head (+1) before the cell, Pc[c] = P at the cell's first byte (tile-local;
+// readers add the scanned tile sums agg_c).  8 bytes per 256 input bytes instead of 8 per byte; a
+// reader that needs P inside a cell recomputes it from the cell's 256 bytes (cell_compute).
+#define K1_CELL 256
+#define K1_CPT (K1_TILE / K1_CELL) // cells per tile
+
+// phase 3: cell records and tile sums of c(i).  Wave-row layout: element (w, k, lane) =
+// base + w*1024 + k*64 + lane; a cell is 4 rows of one wave.
+__global__ __launch_bounds__(256) void k1_cells(const u8 *__restrict__ in, u32 n,
+                                                const u32 *__restrict__ agg_head,
+                                                u32 *__restrict__ Hc, u32 *__restrict__ agg_c,
+                                                u32 *__restrict__ Pc, u16 *__restrict__ P16, u32 tile0) {
     const u32 tile = tile0 + blockIdx.x;
     const u32 base = tile * K1_TILE;
     const int w = wave_id(), lane = lane_id();
@@ -129,10 +134,10 @@ __global__ __launch_bounds__(256) void k1_runs(const u8 *__restrict__ in, u32 n,
         // last head strictly before i (+1)
         u64 below = m & ((1ull << lane) - 1ull);
         u32 prevp1 = below ? (rowbase + (63 - __clzll((unsigned long long)below)) + 1) : carry;
+        if ((k & 3) == 0 && lane == 0 && i < n) Hc[i / K1_CELL] = carry;
         u32 c = 0;
         if (i < n) {
             u32 rsi = head ? i : (prevp1 - 1);
-            rs[i] = rsi;
             if ((i - rsi + 1) % 255u == 0) c = 5;
             if (head && i > 0) c += enc_rem((i - (prevp1 - 1)) % 255u);
         }
@@ -150,18 +155,24 @@ __global__ __launch_bounds__(256) void k1_runs(const u8 *__restrict__ in, u32 n,
     for (int k = 0; k < 16; k++) {
         u32 i = base + w * 1024 + k * 64 + lane;
         u32 inc = wave_incl_scan_add(cv[k]);
-        if (i < n) P[i] = run + inc - cv[k];
+        if ((k & 3) == 0 && lane == 0 && i < n) Pc[i / K1_CELL] = run; // lane 0: exclusive prefix = run
+        if (i < n) P16[i] = (u16)(run + inc - cv[k]); // tile-local: < 1.25 x K1_TILE
         run += __shfl(inc, 63, 64);
     }
 }
 
-// sentinels at position n: rs[n] = n, P(n) = total
-__global__ void k1_sentinels(u32 *rs, u32 *P, u32 *agg_c, u32 n, const u32 *total) {
+// the cell that position n falls into when n is a multiple of the cell: Hc = last head of all
+// (+1), P(n) = total
+__global__ void k1_sentinels(u32 *Hc, u32 *Pc, u16 *P16, u32 *agg_c, const u32 *agg_head_total, u32 n,
+                             const u32 *total) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        rs[n] = n;
         const u32 t = n / K1_TILE;
-        if (n % K1_TILE == 0) agg_c[t] = *total; // tile n falls into does not exist yet
-        P[n] = *total - agg_c[t];
+        if (n % K1_TILE == 0) agg_c[t] = *total; // the tile n falls into does not exist yet
+        P16[n] = (u16)(*total - agg_c[t]);        // P(n) = total
+        if (n % K1_CELL == 0) {
+            Hc[n / K1_CELL] = *agg_head_total;
+            Pc[n / K1_CELL] = *total - agg_c[t];
+        }
     }
 }
 
@@ -170,8 +181,9 @@ struct PlainArr {
     const u32 *a;
     __device__ __forceinline__ u32 operator()(u32 i) const { return a[i]; }
 };
-struct PrefixArr { // absolute flushed-length prefix = tile-local value + scanned tile sum
-    const u32 *P, *agg;
+struct PrefixArr { // absolute flushed-length prefix = tile-local value (16 bits) + scanned tile sum
+    const u16 *P;
+    const u32 *agg;
     __device__ __forceinline__ u32 operator()(u32 i) const { return P[i] + agg[i / K1_TILE]; }
 };
 
@@ -236,6 +248,103 @@ __device__ bool wave_bracket(const ARR arr, u32 lo, u32 hi, u32 thr, u32 *nlo, u
     return true;
 }
 
+// ---------------------------------------------------------------- cells, read side (one wave)
+struct CellArrs {
+    const u8 *in;
+    const u32 *Hc, *Pc, *agg;
+    u32 n;
+};
+struct CellStartP { // P at the first byte of a cell (non-decreasing in the cell index)
+    const u32 *Pc, *agg;
+    __device__ __forceinline__ u32 operator()(u32 c) const { return Pc[c] + agg[c / K1_CPT]; }
+};
+struct CellHeadArr { // last head (+1) before a cell
+    const u32 *Hc;
+    __device__ __forceinline__ u32 operator()(u32 c) const { return Hc[c]; }
+};
+struct CellRaw { // what cell_compute needs from memory: issued together, used after one latency
+    u32 b[4];  // in[c*256 + r*64 + lane]
+    u32 prev0; // in[c*256 - 1]
+    u32 H, P0;
+};
+__device__ __forceinline__ void cell_load(const CellArrs &A, u32 c, CellRaw &R) {
+    const u32 base = c * K1_CELL;
+    const int lane = lane_id();
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const u32 i = base + r * 64 + lane;
+        R.b[r] = A.in[i < A.n ? i : A.n - 1];
+    }
+    R.prev0 = A.in[base ? min(base - 1, A.n - 1) : 0];
+    R.H = A.Hc[c];
+    R.P0 = A.Pc[c] + A.agg[c / K1_CPT];
+}
+// pv[r] = P(c*256 + r*64 + lane) (meaningful for positions <= n); hm[r] = heads of row r.
+// The arithmetic is k1_cells' (same c(i)), started from the cell record.
+__device__ __forceinline__ void cell_compute(const CellArrs &A, u32 c, const CellRaw &R, u32 (&pv)[4],
+                                             u64 (&hm)[4]) {
+    const int lane = lane_id();
+    const u32 base = c * K1_CELL;
+    u32 carry = R.H, run = R.P0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const u32 rowbase = base + r * 64;
+        const u32 i = rowbase + lane;
+        u32 pb = __shfl_up(R.b[r], 1, 64);
+        const u32 edge = r == 0 ? R.prev0 : (u32)__builtin_amdgcn_readlane((int)R.b[r > 0 ? r - 1 : 0], 63);
+        if (lane == 0) pb = edge;
+        const bool head = i < A.n && (i == 0 || R.b[r] != pb);
+        const u64 m = __ballot(head);
+        hm[r] = m;
+        const u64 below = m & ((1ull << lane) - 1ull);
+        const u32 prevp1 = below ? (rowbase + (63 - __clzll((unsigned long long)below)) + 1) : carry;
+        u32 cval = 0;
+        if (i < A.n) {
+            const u32 rsi = head ? i : (prevp1 - 1);
+            if ((i - rsi + 1) % 255u == 0) cval = 5;
+            if (head && i > 0) cval += enc_rem((i - (prevp1 - 1)) % 255u);
+        }
+        const u32 inc = wave_incl_scan_add(cval);
+        pv[r] = run + inc - cval;
+        run += (u32)__builtin_amdgcn_readlane((int)inc, 63);
+        if (m) carry = rowbase + (63 - __clzll((unsigned long long)m)) + 1;
+    }
+}
+// P(x) out of a computed cell (x inside it)
+__device__ __forceinline__ u32 cell_P_at(const u32 (&pv)[4], u32 x) {
+    const u32 r = (x % K1_CELL) / 64, l = x % 64;
+    u32 v = pv[0];
+    if (r == 1) v = pv[1];
+    if (r == 2) v = pv[2];
+    if (r == 3) v = pv[3];
+    return __shfl(v, l, 64);
+}
+// first position i of the cell with P(i) > thr and i <= upto; ~0 if none
+__device__ __forceinline__ u32 cell_first_gt(const u32 (&pv)[4], u32 c, u32 thr, u32 upto) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const u32 i = c * K1_CELL + r * 64 + lane;
+        const u64 m = __ballot(i <= upto && pv[r] > thr);
+        if (m) return c * K1_CELL + r * 64 + (u32)(__ffsll((unsigned long long)m) - 1);
+    }
+    return 0xffffffffu;
+}
+// first head position > s inside cell c (heads of computed rows); ~0 if none
+__device__ __forceinline__ u32 cell_first_head_after(const u64 (&hm)[4], u32 c, u32 s) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const u32 rowbase = c * K1_CELL + r * 64;
+        u64 m = hm[r];
+        if (rowbase <= s) { // drop the positions <= s
+            const u32 cut = s - rowbase + 1;
+            m = cut >= 64 ? 0ull : (m >> cut) << cut;
+        }
+        if (m) return rowbase + (u32)(__ffsll((unsigned long long)m) - 1);
+    }
+    return 0xffffffffu;
+}
+
 // serial chain over blocks; one wave.  starts[k] for k <= count (starts[count] = end of last).
 // The chain is pure memory latency (each block's start is the previous block's end), so a block
 // costs as few dependent loads as possible: the run-end probe also fetches the prefix it will need,
@@ -243,13 +352,16 @@ __device__ bool wave_bracket(const ARR arr, u32 lo, u32 hi, u32 thr, u32 *nlo, u
 // The chain begins at s0 (a block start; a run that straddles s0 is cut there, so nothing before
 // s0 matters) and takes blocks whose start lies below `stop` (sharding: the next shard continues
 // from starts[count]).
-__global__ __launch_bounds__(64) void k1_split(const u32 *__restrict__ rs,
-                                               const u32 *__restrict__ Ploc,
+__global__ __launch_bounds__(64) void k1_split(const u8 *__restrict__ in, const u32 *__restrict__ Hc,
+                                               const u32 *__restrict__ Pc,
+                                               const u16 *__restrict__ Ploc,
                                                const u32 *__restrict__ agg_c, u32 n, u32 block_size,
                                                u32 max_blocks, u32 *__restrict__ starts,
                                                u32 *__restrict__ count_out, u32 s0, u32 stop) {
     const u32 limit = block_size - 6;
     const PrefixArr P{Ploc, agg_c};
+    const CellArrs A{in, Hc, Pc, agg_c, n};
+    const u32 cmax = n / K1_CELL;
     u32 s = s0, cnt = 0, plen = 0, perr = 0;
     while (s < n && s < stop && cnt < max_blocks) {
         if (lane_id() == 0) starts[cnt] = s;
@@ -259,7 +371,9 @@ __global__ __launch_bounds__(64) void k1_split(const u32 *__restrict__ rs,
         bool have_p = false;
         {
             const u32 idx = s + 1u + (u32)lane_id();
-            const bool pred = idx <= n && rs[idx] > s;
+            // a head at idx (the end of the data counts as one)
+            const u32 hb = in[min(idx, n - 1)], hbp = in[min(idx - 1u, n - 1)];
+            const bool pred = idx <= n && (idx == n || hb != hbp);
             const u32 pnext = (idx + 1u <= n) ? P(idx + 1u) : 0u;
             const u64 m = __ballot(pred);
             if (m) {
@@ -267,7 +381,20 @@ __global__ __launch_bounds__(64) void k1_split(const u32 *__restrict__ rs,
                 re0 = s + 1u + (u32)l0;
                 p_re0p1 = __shfl(pnext, l0, 64);
                 have_p = re0 + 1u <= n;
-            } else re0 = (s + 64u >= n) ? n + 1u : wave_search_gt(PlainArr{rs}, s + 64u, n, s);
+            } else {
+                // a long run: the first cell whose "last head before" lies beyond s follows the
+                // cell that holds the run's end
+                const u32 c0 = (s + 64u) / K1_CELL;
+                const u32 c1 = wave_search_gt(CellHeadArr{Hc}, c0, cmax, s + 1u);
+                const u32 c = c1 - 1; // c1 = cmax + 1 when no cell start sees a head beyond s: the last cell
+                CellRaw R;
+                u32 pv[4];
+                u64 hm[4];
+                cell_load(A, c, R);
+                cell_compute(A, c, R, pv, hm);
+                re0 = cell_first_head_after(hm, c, s);
+                if (re0 == 0xffffffffu) re0 = n; // the run reaches the end of the data
+            }
         }
         if (re0 > n) re0 = n;
         u32 e;
@@ -626,7 +753,9 @@ void k1_init_tables(bz2hip_ctx *c) {
     if (c->device >= 0 && c->device < 64) g_crc_tables_ready[c->device] = true;
 }
 
-// Scan a window of input: fills rs[0..n], P[0..n] (asynchronous; independent of where blocks start).
+// Scan a window of input: fills the cell records Hc, Pc (one per 256 bytes, up to the cell of
+// position n), the tile-local 16-bit prefix P16[0..n] (c->w_P16) and the tile aggregates
+// (asynchronous; independent of where blocks start).
 // When the window is still on its way from the host (c->up: bz2hip_compress), it is uploaded in
 // chunks on the copy stream and every chunk is scanned as soon as it has landed, so the transfer
 // of chunk k + 1 runs under the scan of chunk k.
@@ -654,25 +783,26 @@ void run_scan(bz2hip_ctx *c, const u8 *d_in, u32 n, u32 *d_rs, u32 *d_P, u32 *d_
         KCHECK();
         k1_scan_tiles<true><<<1, 1024, 0, c->stream>>>(d_agg1, t0, t1, carry_max);
         KCHECK();
-        k1_runs<<<t1 - t0, 256, 0, c->stream>>>(d_in, upto, d_agg1, d_rs, d_agg2, d_P, t0);
+        k1_cells<<<t1 - t0, 256, 0, c->stream>>>(d_in, upto, d_agg1, d_rs, d_agg2, d_P, c->w_P16, t0);
         KCHECK();
     }
     c->up.active = false;
     k1_scan_tiles<false><<<1, 1024, 0, c->stream>>>(d_agg2, 0, tiles, B.ctl + 8);
     KCHECK();
-    k1_sentinels<<<1, 64, 0, c->stream>>>(d_rs, d_P, d_agg2, n, B.ctl + 8);
+    k1_sentinels<<<1, 64, 0, c->stream>>>(d_rs, d_P, c->w_P16, d_agg2, carry_max, n, B.ctl + 8);
     KCHECK();
 }
 
 // The serial block chain over a scanned window, from block start s0, for blocks that start below
 // `stop`.  Returns the number of blocks found (<= max_blocks); h_starts receives count+1 offsets
 // (h_starts[count] = end of the last block = start of the next).
-u32 run_chain(bz2hip_ctx *c, u32 n, int level, const u32 *d_rs, const u32 *d_P, const u32 *d_agg2,
-              u32 *d_starts, u32 max_blocks, u32 s0, u32 stop, std::vector<u32> &h_starts) {
+u32 run_chain(bz2hip_ctx *c, const u8 *d_in, u32 n, int level, const u32 *d_rs, const u32 *d_P,
+              const u32 *d_agg2, u32 *d_starts, u32 max_blocks, u32 s0, u32 stop,
+              std::vector<u32> &h_starts) {
     Batch &B = c->batch;
     {
         ProfScope ps(c, P_RLE1_SPLIT, 0);
-        k1_split<<<1, 64, 0, c->stream>>>(d_rs, d_P, d_agg2, n, (u32)level * 100000u, max_blocks, d_starts,
+        k1_split<<<1, 64, 0, c->stream>>>(d_in, d_rs, d_P, c->w_P16, d_agg2, n, (u32)level * 100000u, max_blocks, d_starts,
                                           B.ctl + 9, s0, stop);
         KCHECK();
     }
@@ -689,7 +819,7 @@ u32 run_chain(bz2hip_ctx *c, u32 n, int level, const u32 *d_rs, const u32 *d_P, 
 u32 run_split(bz2hip_ctx *c, const u8 *d_in, u32 n, int level, u32 *d_rs, u32 *d_P, u32 *d_agg1,
               u32 *d_agg2, u32 *d_starts, u32 max_blocks, std::vector<u32> &h_starts) {
     run_scan(c, d_in, n, d_rs, d_P, d_agg1, d_agg2);
-    return run_chain(c, n, level, d_rs, d_P, d_agg2, d_starts, max_blocks, 0, n, h_starts);
+    return run_chain(c, d_in, n, level, d_rs, d_P, d_agg2, d_starts, max_blocks, 0, n, h_starts);
 }
 
 // CRC of nb byte ranges [starts[b], starts[b+1]) of d_data (the decoder's use of the CRC kernels)
