@@ -89,75 +89,106 @@ __global__ __launch_bounds__(1024) void k1_scan_tiles(u32 *__restrict__ agg, u32
 #define K1_CELL 256
 #define K1_CPT (K1_TILE / K1_CELL) // cells per tile
 
-// phase 3: cell records and tile sums of c(i).  Wave-row layout: element (w, k, lane) =
-// base + w*1024 + k*64 + lane; a cell is 4 rows of one wave.
+// phase 3: cell records, the 16-bit prefix and tile sums of c(i).  Every thread owns 16 consecutive
+// bytes (one 16-byte load) and walks them with the chunk phase L = (i - rs(i)) % 255 in a register
+// (no division per byte); the run start that enters a thread comes from a max-scan of "last head"
+// over the threads before it, the prefix from a scan of the threads' sums.
 __global__ __launch_bounds__(256) void k1_cells(const u8 *__restrict__ in, u32 n,
                                                 const u32 *__restrict__ agg_head,
                                                 u32 *__restrict__ Hc, u32 *__restrict__ agg_c,
                                                 u32 *__restrict__ Pc, u16 *__restrict__ P16, u32 tile0) {
     const u32 tile = tile0 + blockIdx.x;
-    const u32 base = tile * K1_TILE;
-    const int w = wave_id(), lane = lane_id();
-    __shared__ u32 wlast[4];
-    __shared__ u32 wsum[4];
-    u64 hm[16];
-    u32 last = 0;
-    u8 c0[16], c1[16];
+    const u32 pos = tile * K1_TILE + threadIdx.x * 16u;
+    const int lane = lane_id(), wv = wave_id();
+    __shared__ u32 sm[8];
+    __shared__ u32 red[8];
+    u32 w[4];
+    if (pos + 16u <= n && (((uintptr_t)(in + pos)) & 15u) == 0) {
+        const uint4 v = *(const uint4 *)(in + pos);
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    } else {
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const u32 i = base + w * 1024 + k * 64 + lane;
-        const u32 ic = i < n ? i : n - 1;
-        c0[k] = in[ic];
-        c1[k] = in[ic ? ic - 1 : 0];
-    }
+        for (int q = 0; q < 4; q++) {
+            u32 x = 0;
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        u32 i = base + w * 1024 + k * 64 + lane;
-        bool head = false;
-        if (i < n) head = (i == 0) || (c0[k] != c1[k]);
-        u64 m = __ballot(head);
-        hm[k] = m;
-        if (m) last = base + w * 1024 + k * 64 + (63 - __clzll((unsigned long long)m)) + 1;
+            for (int j = 0; j < 4; j++) {
+                const u32 i = pos + q * 4 + j;
+                if (i < n) x |= (u32)in[i] << (8 * j);
+            }
+            w[q] = x;
+        }
     }
-    if (lane == 0) wlast[w] = last;
+    u32 prv = __shfl_up(w[3] >> 24, 1, 64);
+    if (lane == 0 && pos > 0 && pos < n) prv = in[pos - 1];
+    u32 heads = 0, lastp1 = 0;
+    {
+        u32 pb = prv;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const u32 i = pos + j;
+            const u32 c = (w[j >> 2] >> (8 * (j & 3))) & 255u;
+            if (i < n && (i == 0 || c != pb)) {
+                heads |= 1u << j;
+                lastp1 = i + 1;
+            }
+            pb = c;
+        }
+    }
+    // last head (+1) before this thread
+    const u32 inc = wave_incl_scan_max(lastp1);
+    if (lane == 63) sm[wv] = inc;
     __syncthreads();
-    u32 carry = agg_head[tile]; // last head (+1) before this tile
-    for (int q = 0; q < w; q++) carry = max(carry, wlast[q]);
-    u32 cv[16];
-    u32 wtot = 0;
+    u32 carry = agg_head[tile];
+    for (int q = 0; q < wv; q++) carry = max(carry, sm[q]);
+    const u32 up = __shfl_up(inc, 1, 64);
+    if (lane > 0) carry = max(carry, up);
+    // c(i) of the 16 bytes: 4 bits each (c <= 10)
+    u32 L = carry ? (pos - (carry - 1u)) % 255u : 0u; // bytes of the entering run's current chunk
+    u64 cpack = 0;
+    u32 tot = 0;
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        u32 rowbase = base + w * 1024 + k * 64;
-        u32 i = rowbase + lane;
-        u64 m = hm[k];
-        bool head = (m >> lane) & 1ull;
-        // last head strictly before i (+1)
-        u64 below = m & ((1ull << lane) - 1ull);
-        u32 prevp1 = below ? (rowbase + (63 - __clzll((unsigned long long)below)) + 1) : carry;
-        if ((k & 3) == 0 && lane == 0 && i < n) Hc[i / K1_CELL] = carry;
+    for (int j = 0; j < 16; j++) {
+        const u32 i = pos + j;
         u32 c = 0;
         if (i < n) {
-            u32 rsi = head ? i : (prevp1 - 1);
-            if ((i - rsi + 1) % 255u == 0) c = 5;
-            if (head && i > 0) c += enc_rem((i - (prevp1 - 1)) % 255u);
+            if ((heads >> j) & 1u) {
+                if (i > 0) c = enc_rem(L); // remainder of the run that ended at i - 1
+                L = 0;
+            }
+            if (++L == 255u) { // a full chunk is flushed with this byte
+                c += 5u;
+                L = 0;
+            }
         }
-        cv[k] = c;
-        wtot += c;
-        if (m) carry = rowbase + (63 - __clzll((unsigned long long)m)) + 1;
+        cpack |= (u64)c << (4 * j);
+        tot += c;
     }
-    wtot = wave_reduce_add(wtot);
-    if (lane == 0) wsum[w] = wtot;
-    __syncthreads();
-    if (threadIdx.x == 0) agg_c[tile] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    u32 run = 0;
-    for (int q = 0; q < w; q++) run += wsum[q];
+    u32 total;
+    const u32 base = block_excl_scan_add<256>(tot, red, &total);
+    if (threadIdx.x == 0) agg_c[tile] = total;
+    if ((threadIdx.x & 15u) == 0 && pos < n) {
+        Hc[pos / K1_CELL] = carry;
+        Pc[pos / K1_CELL] = base;
+    }
+    // tile-local prefix per byte (< 1.25 x K1_TILE: 16 bits)
+    u32 run = base;
+    u32 o[8];
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        u32 i = base + w * 1024 + k * 64 + lane;
-        u32 inc = wave_incl_scan_add(cv[k]);
-        if ((k & 3) == 0 && lane == 0 && i < n) Pc[i / K1_CELL] = run; // lane 0: exclusive prefix = run
-        if (i < n) P16[i] = (u16)(run + inc - cv[k]); // tile-local: < 1.25 x K1_TILE
-        run += __shfl(inc, 63, 64);
+    for (int j = 0; j < 16; j += 2) {
+        const u32 p0 = run;
+        run += (u32)(cpack >> (4 * j)) & 15u;
+        const u32 p1 = run;
+        run += (u32)(cpack >> (4 * j + 4)) & 15u;
+        o[j >> 1] = p0 | (p1 << 16);
+    }
+    if (pos + 16u <= n) {
+        uint4 *dst = (uint4 *)(P16 + pos);
+        dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+        dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            if (pos + j < n) P16[pos + j] = (u16)(o[j >> 1] >> (16 * (j & 1)));
     }
 }
 
