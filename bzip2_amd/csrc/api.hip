@@ -126,6 +126,7 @@ static void wfree(bz2hip_ctx *c) {
     c->w_region = c->w_eregion = nullptr;
     c->w_rs = c->w_P = c->w_agg1 = c->w_agg2 = c->w_starts = c->w_eagg = c->w_cagg = nullptr;
     c->w_P16 = nullptr;
+    c->w_binfo = nullptr;
 }
 
 static u32 window_max_blocks(size_t wlen, int level) {
@@ -146,7 +147,8 @@ static size_t layout_window(bz2hip_ctx *c, size_t wlen, u32 mb, u8 *base) {
     u32 *rs = A.get<u32>(cells), *P = A.get<u32>(cells);
     u16 *p16 = A.get<u16>(wlen + 16);
     u32 *a1 = A.get<u32>(tiles), *a2 = A.get<u32>(tiles), *st = A.get<u32>((size_t)mb + 8);
-    if (base) { c->w_rs = rs; c->w_P = P; c->w_P16 = p16; c->w_agg1 = a1; c->w_agg2 = a2; c->w_starts = st; }
+    u32 *bi = A.get<u32>(2 * ((size_t)mb + 8));
+    if (base) { c->w_rs = rs; c->w_P = P; c->w_P16 = p16; c->w_binfo = bi; c->w_agg1 = a1; c->w_agg2 = a2; c->w_starts = st; }
     return A.off;
 }
 // per-batch emit / CRC tile partials
@@ -460,7 +462,7 @@ static void compress_window_blocks(bz2hip_ctx *c, const u8 *d_win, const std::ve
         const int nb = (int)std::min<u32>(bsz, usable - b0);
         u32 max_in = 0;
         for (int b = 0; b < nb; b++) max_in = std::max(max_in, starts[b0 + b + 1] - starts[b0 + b]);
-        run_rle1_emit(c, d_win, c->w_agg1, c->w_starts, b0, nb, max_in, c->w_eagg, c->w_ETPB);
+        run_rle1_emit(c, d_win, c->w_agg1, c->w_starts, b0, nb, max_in, c->w_ETPB);
         run_bwt_n(c, nb, bs);
         run_mtf(c, nb, bs);
         run_huffman(c, nb, bs + 1);
@@ -568,6 +570,7 @@ extern "C" int bz2hip_compress_device_noalloc(bz2hip_ctx *c, const void *d_in, s
             Batch batch;
             u32 *w_rs, *w_P, *w_agg1, *w_agg2, *w_starts, *w_eagg, *w_cagg;
             u16 *w_P16;
+            u32 *w_binfo;
             size_t w_cap;
             u32 w_maxblocks, w_ETPB;
             int w_eagg_nb;
@@ -575,7 +578,7 @@ extern "C" int bz2hip_compress_device_noalloc(bz2hip_ctx *c, const void *d_in, s
             explicit Saved(bz2hip_ctx *cc)
                 : c(cc), batch(std::move(cc->batch)), w_rs(cc->w_rs), w_P(cc->w_P), w_agg1(cc->w_agg1),
                   w_agg2(cc->w_agg2), w_starts(cc->w_starts), w_eagg(cc->w_eagg), w_cagg(cc->w_cagg),
-                  w_P16(cc->w_P16), w_cap(cc->w_cap), w_maxblocks(cc->w_maxblocks), w_ETPB(cc->w_ETPB),
+                  w_P16(cc->w_P16), w_binfo(cc->w_binfo), w_cap(cc->w_cap), w_maxblocks(cc->w_maxblocks), w_ETPB(cc->w_ETPB),
                   w_eagg_nb(cc->w_eagg_nb), profile(cc->profile) {
                 cc->batch = Batch();
                 cc->fixed_ws = true;
@@ -586,6 +589,7 @@ extern "C" int bz2hip_compress_device_noalloc(bz2hip_ctx *c, const void *d_in, s
                 c->w_rs = w_rs; c->w_P = w_P; c->w_agg1 = w_agg1; c->w_agg2 = w_agg2;
                 c->w_starts = w_starts; c->w_eagg = w_eagg; c->w_cagg = w_cagg;
                 c->w_P16 = w_P16;
+                c->w_binfo = w_binfo;
                 c->w_cap = w_cap; c->w_maxblocks = w_maxblocks; c->w_ETPB = w_ETPB;
                 c->w_eagg_nb = w_eagg_nb;
                 c->profile = profile;
@@ -1491,7 +1495,7 @@ extern "C" int bz2hip_rle1_split(bz2hip_ctx *c, const uint8_t *in, size_t n, int
                     int nb = (int)std::min<u32>((u32)B.NB, usable - b0);
                     u32 max_in = 0;
                     for (int b = 0; b < nb; b++) max_in = std::max(max_in, hs[b0 + b + 1] - hs[b0 + b]);
-                    run_rle1_emit(c, c->h_in, c->w_agg1, c->w_starts, b0, nb, max_in, c->w_eagg, c->w_ETPB);
+                    run_rle1_emit(c, c->h_in, c->w_agg1, c->w_starts, b0, nb, max_in, c->w_ETPB);
                     HIPCHK(hipStreamSynchronize(c->stream));
                     const size_t o = (size_t)total + b0;
                     HIPCHK(hipMemcpy2D(rle + o * rstride, rstride, B.T, B.S, bs, nb, hipMemcpyDeviceToHost));

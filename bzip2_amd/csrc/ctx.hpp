@@ -141,6 +141,7 @@ struct bz2hip_ctx {
     // window scratch for K1 (split / RLE1 / CRC)
     u32 *w_rs = nullptr, *w_P = nullptr, *w_agg1 = nullptr, *w_agg2 = nullptr;
     u32 *w_starts = nullptr, *w_eagg = nullptr;
+    u32 *w_binfo = nullptr;  // per block: end of its first run, P just after it (k1_split -> k1_emit)
     u16 *w_P16 = nullptr;    // flushed-length prefix per input byte, tile-local (k1_rle1.hip)
     u32 *w_cagg = nullptr;   // CRC tile partials (same shape as w_eagg; used on the other stream)
     void *w_region = nullptr;  // device region holding rs / P / aggregates / starts
@@ -301,4 +302,4 @@ u32 run_chain(bz2hip_ctx *c, const u8 *d_in, u32 n, int level, const u32 *d_rs, 
 u32 run_split(bz2hip_ctx *c, const u8 *d_in, u32 n, int level, u32 *d_rs, u32 *d_P, u32 *d_agg1,
               u32 *d_agg2, u32 *d_starts, u32 max_blocks, std::vector<u32> &h_starts);
 void run_rle1_emit(bz2hip_ctx *c, const u8 *d_in, const u32 *d_agg_head, const u32 *d_starts, u32 b0,
-                   int nb, u32 max_in_len, u32 *d_eagg, u32 ETPB);
+                   int nb, u32 max_in_len, u32 ETPB);

@@ -388,6 +388,7 @@ __global__ __launch_bounds__(64) void k1_split(const u8 *__restrict__ in, const 
                                                const u16 *__restrict__ Ploc,
                                                const u32 *__restrict__ agg_c, u32 n, u32 block_size,
                                                u32 max_blocks, u32 *__restrict__ starts,
+                                               u32 *__restrict__ binfo,
                                                u32 *__restrict__ count_out, u32 s0, u32 stop) {
     const u32 limit = block_size - 6;
     const PrefixArr P{Ploc, agg_c};
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(64) void k1_split(const u8 *__restrict__ in, const 
             }
         }
         if (re0 > n) re0 = n;
-        u32 e;
+        u32 e, pre = 0;
         u32 cand = s + 255u * (limit / 5u + 1u);
         if (cand <= re0 && cand > s) {
             e = cand;
@@ -444,7 +445,8 @@ __global__ __launch_bounds__(64) void k1_split(const u8 *__restrict__ in, const 
             if (enc0 > limit) {
                 e = re0 + 1; // the first run alone overfills: refused right after the next head
             } else {
-                const u32 thr = limit - enc0 + (have_p ? p_re0p1 : P(re0 + 1));
+                pre = have_p ? p_re0p1 : P(re0 + 1);
+                const u32 thr = limit - enc0 + pre;
                 // blocks of one kind of data are about equally long.  When the last block was as long as
                 // the one before (run-free data: always bs - 4 bytes), one probe of the 64 positions
                 // around "as long again" settles this block in a single dependent load.
@@ -476,6 +478,11 @@ __global__ __launch_bounds__(64) void k1_split(const u8 *__restrict__ in, const 
                     if (e > hi) e = (hi == n) ? n : hi; // not expected when hi < n
                 }
             }
+        }
+        // for the emit: where the block's first run ends and P just after it (k1_emit)
+        if (lane_id() == 0) {
+            binfo[2 * cnt] = re0;
+            binfo[2 * cnt + 1] = pre;
         }
         cnt++;
         perr = (e - s > plen) ? (e - s - plen) : (plen - (e - s));
@@ -572,54 +579,41 @@ __device__ __forceinline__ u32 emit_lane(const u8 *__restrict__ in, const u32 *_
     return tot;
 }
 
-__global__ __launch_bounds__(256) void k1_emit_p1(const u8 *__restrict__ in,
-                                                  const u32 *__restrict__ agg_head,
-                                                  const u32 *__restrict__ starts,
-                                                  u32 *__restrict__ eagg, u32 ETPB) {
-    const u32 b = blockIdx.y;
-    const u32 s = starts[b], e = starts[b + 1];
-    const u32 gt = s / K1_TILE + blockIdx.x;
-    if (gt * K1_TILE >= e) return;
-    __shared__ u32 sm[8];
-    __shared__ u32 red[8];
-    EmitLane L;
-    const u32 tot = emit_lane(in, agg_head, s, e, gt, sm, L);
-    const u32 t = block_reduce_add<256>(tot, red);
-    if (threadIdx.x == 0) eagg[(size_t)b * ETPB + blockIdx.x] = t;
-}
-
-__global__ __launch_bounds__(256) void k1_emit_p2(const u32 *__restrict__ starts,
-                                                  u32 *__restrict__ eagg, u32 *__restrict__ nOut,
-                                                  u32 *__restrict__ present, u32 ETPB) {
-    const u32 b = blockIdx.x;
-    // global tiles the block touches
-    const u32 sb = starts[b], eb = starts[b + 1];
-    const u32 tiles = eb > sb ? (eb - 1) / K1_TILE - sb / K1_TILE + 1 : 0;
-    __shared__ u32 sm[8];
-    u32 carry = 0;
-    for (u32 t0 = 0; t0 < tiles; t0 += 256) {
-        u32 t = t0 + threadIdx.x;
-        u32 v = (t < tiles) ? eagg[(size_t)b * ETPB + t] : 0;
-        u32 tot;
-        u32 ex = block_excl_scan_add<256>(v, sm, &tot);
-        if (t < tiles) eagg[(size_t)b * ETPB + t] = carry + ex;
-        carry += tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) nOut[b] = carry;
-    if (threadIdx.x < 8) present[b * 8 + threadIdx.x] = 0;
-}
-
 #define K1_EMIT_STAGE (K1_TILE + K1_TILE / 4 + 64) // a run of 4 emits 5 bytes: at most 1.25 per input byte
-__global__ __launch_bounds__(256) void k1_emit_p3(const u8 *__restrict__ in,
-                                                  const u32 *__restrict__ agg_head,
-                                                  const u32 *__restrict__ starts,
-                                                  const u32 *__restrict__ eagg, u8 *__restrict__ T,
-                                                  u32 *__restrict__ present, u32 S, u32 ETPB) {
+// Bytes the block has emitted before the tile's first byte a, without a pass over the tiles before:
+// inside the block's first run (a <= re0) that is 5 per full 255-chunk plus the open chunk; after
+// it, enc(first run) + P(a) - P(re0 + 1) -- the flushed-length prefix the scan already holds at
+// tile starts (agg_c) and the split recorded per block (binfo) -- plus the open chunk of the run
+// that enters the tile.  An open chunk of k bytes has emitted min(k, 4) bytes, and its count byte
+// too once the run has ended (a is a head).
+__device__ __forceinline__ u32 emit_base(const u8 *__restrict__ in, const u32 *__restrict__ agg_head,
+                                         const u32 *__restrict__ agg_c, const u32 *__restrict__ binfo,
+                                         u32 b, u32 s, u32 gt) {
+    const u32 a = gt * K1_TILE;
+    if (a <= s) return 0;
+    const u32 re0 = binfo[2 * b], pre = binfo[2 * b + 1];
+    const bool head = in[a] != in[a - 1];
+    if (a <= re0) {
+        const u32 L = a - s, k = L % 255u;
+        return 5u * (L / 255u) + (head ? enc_rem(k) : min(k, 4u));
+    }
+    const u32 L0 = re0 - s;
+    const u32 enc0 = 5u * (L0 / 255u) + enc_rem(L0 % 255u);
+    const u32 k = (a - (agg_head[gt] - 1u)) % 255u;
+    return enc0 + (agg_c[gt] - pre) + (head ? enc_rem(k) : min(k, 4u));
+}
+
+__global__ __launch_bounds__(256) void k1_emit(const u8 *__restrict__ in,
+                                               const u32 *__restrict__ agg_head,
+                                               const u32 *__restrict__ agg_c,
+                                               const u32 *__restrict__ starts,
+                                               const u32 *__restrict__ binfo, u8 *__restrict__ T,
+                                               u32 *__restrict__ present, u32 *__restrict__ nOut, u32 S) {
     const u32 b = blockIdx.y;
     const u32 s = starts[b], e = starts[b + 1];
     const u32 gt = s / K1_TILE + blockIdx.x;
     if (gt * K1_TILE >= e) return;
+    const u32 ebase = emit_base(in, agg_head, agg_c, binfo, b, s, gt);
     __shared__ u32 sm[8];
     __shared__ u32 red[8];
     __shared__ u32 pres[8];
@@ -654,8 +648,9 @@ __global__ __launch_bounds__(256) void k1_emit_p3(const u8 *__restrict__ in,
         }
     }
     __syncthreads();
-    u8 *out = T + (size_t)b * S + eagg[(size_t)b * ETPB + blockIdx.x];
+    u8 *out = T + (size_t)b * S + ebase;
     for (u32 q = threadIdx.x; q < total; q += 256) out[q] = stage[q];
+    if (threadIdx.x == 0 && gt == (e - 1) / K1_TILE) nOut[b] = ebase + total; // the block's last tile
     if (threadIdx.x < 8 && pres[threadIdx.x]) atomicOr(&present[b * 8 + threadIdx.x], pres[threadIdx.x]);
 }
 
@@ -833,7 +828,7 @@ u32 run_chain(bz2hip_ctx *c, const u8 *d_in, u32 n, int level, const u32 *d_rs, 
     Batch &B = c->batch;
     {
         ProfScope ps(c, P_RLE1_SPLIT, 0);
-        k1_split<<<1, 64, 0, c->stream>>>(d_in, d_rs, d_P, c->w_P16, d_agg2, n, (u32)level * 100000u, max_blocks, d_starts,
+        k1_split<<<1, 64, 0, c->stream>>>(d_in, d_rs, d_P, c->w_P16, d_agg2, n, (u32)level * 100000u, max_blocks, d_starts, c->w_binfo,
                                           B.ctl + 9, s0, stop);
         KCHECK();
     }
@@ -867,7 +862,7 @@ void run_crc_blocks(bz2hip_ctx *c, const u8 *d_data, const u32 *d_starts, int nb
 
 // RLE1-encode blocks [b0, b0+nb) of the window into the batch; CRC per block.
 void run_rle1_emit(bz2hip_ctx *c, const u8 *d_in, const u32 *d_agg_head, const u32 *d_starts, u32 b0,
-                   int nb, u32 max_in_len, u32 *d_eagg, u32 ETPB) {
+                   int nb, u32 max_in_len, u32 ETPB) {
     Batch &B = c->batch;
     const u32 tiles = (max_in_len + K1_TILE - 1) / K1_TILE;
     dim3 grid(tiles, nb);
@@ -884,12 +879,9 @@ void run_rle1_emit(bz2hip_ctx *c, const u8 *d_in, const u32 *d_agg_head, const u
     }
     {
         ProfScope ps(c, P_RLE1_EMIT, 0);
-        k1_emit_p1<<<egrid, 256, 0, c->stream>>>(d_in, d_agg_head, d_starts + b0, d_eagg, ETPB);
-        KCHECK();
-        k1_emit_p2<<<nb, 256, 0, c->stream>>>(d_starts + b0, d_eagg, B.n, B.present, ETPB);
-        KCHECK();
-        k1_emit_p3<<<egrid, 256, 0, c->stream>>>(d_in, d_agg_head, d_starts + b0, d_eagg, B.T, B.present,
-                                                B.S, ETPB);
+        HIPCHK(hipMemsetAsync(B.present, 0, (size_t)nb * 8 * sizeof(u32), c->stream));
+        k1_emit<<<egrid, 256, 0, c->stream>>>(d_in, d_agg_head, c->w_agg2, d_starts + b0,
+                                              c->w_binfo + 2 * (size_t)b0, B.T, B.present, B.n, B.S);
         KCHECK();
     }
     HIPCHK(hipStreamWaitEvent(c->stream, c->crc_done, 0));
