@@ -617,7 +617,7 @@ __global__ __launch_bounds__(256) void k1_emit(const u8 *__restrict__ in,
     __shared__ u32 sm[8];
     __shared__ u32 red[8];
     __shared__ u32 pres[8];
-    __shared__ u8 stage[K1_EMIT_STAGE];
+    __shared__ __attribute__((aligned(16))) u8 stage[K1_EMIT_STAGE];
     if (threadIdx.x < 8) pres[threadIdx.x] = 0;
     EmitLane L;
     const u32 tot = emit_lane(in, agg_head, s, e, gt, sm, L);
@@ -649,7 +649,23 @@ __global__ __launch_bounds__(256) void k1_emit(const u8 *__restrict__ in,
     }
     __syncthreads();
     u8 *out = T + (size_t)b * S + ebase;
-    for (u32 q = threadIdx.x; q < total; q += 256) out[q] = stage[q];
+    // copy out: single bytes up to the first 4-byte boundary of the destination and after the
+    // last, whole words in between (two aligned LDS words funnel-shifted per destination word)
+    {
+        const u32 mis = (u32)((4u - ((uintptr_t)out & 3u)) & 3u); // bytes before the first boundary
+        const u32 headn = min(mis, total);
+        if (threadIdx.x < headn) out[threadIdx.x] = stage[threadIdx.x];
+        const u32 nwords = (total - headn) / 4u;
+        u32 *outw = (u32 *)(out + headn);
+        const u32 *st32 = (const u32 *)stage; // stage is 16-byte aligned
+        const u32 sh = headn & 3u;            // stage offset of destination word d is headn + 4 d
+        for (u32 d = threadIdx.x; d < nwords; d += 256) {
+            const u32 lo = st32[d + (headn >> 2)], hi = st32[d + (headn >> 2) + 1];
+            outw[d] = sh ? (u32)((((u64)hi << 32) | lo) >> (8u * sh)) : lo;
+        }
+        const u32 done = headn + nwords * 4u;
+        if (threadIdx.x < total - done) out[done + threadIdx.x] = stage[done + threadIdx.x];
+    }
     if (threadIdx.x == 0 && gt == (e - 1) / K1_TILE) nOut[b] = ebase + total; // the block's last tile
     if (threadIdx.x < 8 && pres[threadIdx.x]) atomicOr(&present[b * 8 + threadIdx.x], pres[threadIdx.x]);
 }
