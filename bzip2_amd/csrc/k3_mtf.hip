@@ -167,6 +167,10 @@ __global__ __launch_bounds__(256) void k3_mtf_recency(const u8 *__restrict__ bwt
     if (cbase >= n) return;
     const u32 cend = min(cbase + MTF_CHUNK, n);
     const u8 *src = bwt + (size_t)b * S;
+    // The recency list holds the chunk's symbols by last occurrence, latest first.  An element is
+    // its symbol's last occurrence iff the LDS maximum equals its position; its place in the list
+    // is the number of such elements after it: rows from the last to the first, ballot + popcount.
+    u8 sy[MTF_CHUNK / 64];
     {
         u8 rowv[MTF_CHUNK / 64];
 #pragma unroll
@@ -174,30 +178,23 @@ __global__ __launch_bounds__(256) void k3_mtf_recency(const u8 *__restrict__ bwt
 #pragma unroll
         for (int r = 0; r < MTF_CHUNK / 64; r++) {
             const u32 j = cbase + r * 64 + lane;
-            if (j < cend) atomicMax(&last[w][smap[rowv[r]]], j - cbase + 1);
+            sy[r] = smap[rowv[r]];
+            if (j < cend) atomicMax(&last[w][sy[r]], j - cbase + 1);
         }
     }
     // wave-local: LDS operations of one wave complete in order
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
-    u32 mine[4], r[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int k = 0; k < 4; k++) mine[k] = last[w][lane * 4 + k];
-    const uint4 *lv = (const uint4 *)&last[w][0];
-    for (int t = 0; t < 64; t++) {
-        uint4 v = lv[t];
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            r[k] += (v.x > mine[k]) + (v.y > mine[k]) + (v.z > mine[k]) + (v.w > mine[k]);
-    }
     u32 d = 0;
+    const u64 after = lane == 63 ? 0ull : (~0ull << (lane + 1));
 #pragma unroll
-    for (int k = 0; k < 4; k++)
-        if (mine[k]) {
-            recl[w][r[k]] = (u8)(lane * 4 + k);
-            d++;
-        }
-    d = wave_reduce_add(d);
+    for (int r = MTF_CHUNK / 64 - 1; r >= 0; r--) {
+        const u32 j = cbase + r * 64 + lane;
+        const bool fl = j < cend && last[w][sy[r]] == j - cbase + 1;
+        const u64 m = __ballot(fl);
+        if (fl) recl[w][d + (u32)__popcll(m & after)] = sy[r];
+        d += (u32)__popcll(m);
+    }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
     ((u32 *)(mtfrec + ((size_t)b * CPB + c) * 256))[lane] = ((const u32 *)&recl[w][0])[lane];
