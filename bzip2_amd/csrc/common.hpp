@@ -15,6 +15,13 @@ typedef uint64_t u64;
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
+// v_writelane_b32: lane `l` of `old` := the uniform value `v` (the compiler's intrinsic, which this
+// clang has no builtin for; it routes the lane select through M0 and places the wait states)
+extern "C" __device__ int bz2_writelane_i32(int, int, int) __asm("llvm.amdgcn.writelane.i32");
+__device__ __forceinline__ u32 write_lane(u32 old, u32 v, int l) {
+    return (u32)bz2_writelane_i32((int)v, l, (int)old);
+}
+
 __device__ __forceinline__ u32 wave_incl_scan_add(u32 v) {
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {

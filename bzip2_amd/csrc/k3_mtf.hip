@@ -43,12 +43,6 @@ __device__ __forceinline__ void build_symbol_map(const u32 *__restrict__ present
 // occur sit at the end of every entry list (the recency operator only moves present symbols to the
 // front) and keep the lowest times, so they never count towards a position: a block of <= 128
 // symbols (text) needs 2 compares + 2 popcounts per run head, one of <= 64 (DNA, Markov) 1.
-// v_writelane_b32: lane `l` of `old` := the uniform value `v` (the compiler's intrinsic, which this
-// clang has no builtin for; it routes the lane select through M0 and places the wait states)
-extern "C" __device__ int bz2_writelane_i32(int, int, int) __asm("llvm.amdgcn.writelane.i32");
-__device__ __forceinline__ u32 write_lane(u32 old, u32 v, int l) {
-    return (u32)bz2_writelane_i32((int)v, l, (int)old);
-}
 
 template <int NSYM>
 __device__ __forceinline__ void mtf_replay_body(const u8 *__restrict__ src, u32 cbase, u32 cend,

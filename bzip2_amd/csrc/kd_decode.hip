@@ -114,6 +114,18 @@ struct KdBits {
         fill();
         skip((int)(bit & 31u));
     }
+    // The reader's state is the same in every lane, but the compiler cannot always prove it (a
+    // value that meets a lane-dependent branch anywhere is kept in vector registers, and loops over
+    // it then run with exec masks and VALU compares, ~25 instructions per step instead of ~10):
+    // pin it to scalar registers.
+    __device__ __forceinline__ static u64 uni64(u64 v) {
+        return ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(v >> 32)) << 32) |
+               (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)v);
+    }
+    __device__ __forceinline__ void pin() {
+        hi = uni64(hi); lo = uni64(lo); wpos = uni64(wpos); wbase = uni64(wbase);
+        bc = __builtin_amdgcn_readfirstlane(bc);
+    }
     __device__ __forceinline__ u32 peek(int k) { return k ? (u32)(hi >> (64 - k)) : 0u; } // k <= 32
     __device__ __forceinline__ void skip(int k) { // k <= 127
         const unsigned __int128 t = (((unsigned __int128)hi << 64) | lo) << k;
@@ -304,6 +316,14 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
             int gleft = 0, gidx = -1, cur = sel[0];
             u32 stop = 0; // 0: running, 1: the final ring entry is among those being written, 2: gave up
             while (!stop) {
+                // wave-uniform state in scalar registers (see KdBits::pin)
+                br.pin();
+                gleft = __builtin_amdgcn_readfirstlane(gleft);
+                gidx = __builtin_amdgcn_readfirstlane(gidx);
+                cur = __builtin_amdgcn_readfirstlane(cur);
+                head = (u32)__builtin_amdgcn_readfirstlane((int)head);
+                tail_seen = (u32)__builtin_amdgcn_readfirstlane((int)tail_seen);
+                published = (u32)__builtin_amdgcn_readfirstlane((int)published);
                 u32 mysym = 0, cnt = 0;
                 u64 visited = 0;
                 bool fast = false;
@@ -399,7 +419,7 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                     for (;;) {
                         tail_seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_tail, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
                         if (head + cnt - tail_seen <= KD_RING) break;
-                        if (__hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ||
+                        if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) ||
                             ++spins > KD_SPIN_MAX) { stop = 2; break; }
                         __builtin_amdgcn_s_sleep(2);
                     }
@@ -426,6 +446,10 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
             // ---- consumer: symbols -> BWT bytes, S/BZip2BlockDecompressor.swift:266-321.  The MTF
             // list holds the bytes themselves (the symbol map applied to the identity list).
             u32 L = ((const u32 *)symmap)[lane];
+            // F = the list's first four entries (lane 0's word) in a scalar register; while fdirty,
+            // F is ahead of lane 0 of L
+            u32 F = (u32)__builtin_amdgcn_readlane((int)L, 0);
+            bool fdirty = false;
             u32 rep = 0, inc = 1, curbyte = symmap[0], len = 0, pend = 0;
             u32 tail = 0, status = KS_OK;
             bool done = false;
@@ -446,11 +470,42 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                 const u64 plain = __ballot(mine >= 2u && mine < KD_SYM_ERR && (int)mine != eob);
                 const u32 pq = (mine - 1u) & 255u;
                 const u32 pk = (pq >> 2) | ((pq & 3u) << 11); // lane | byte shift << 8
-                bool room = len + avail <= block_size;
-                for (u32 q = 0; q < avail && !done; q++) {
-                    if (rep == 0 && room) {
-                        // the common case: a stretch of plain MTF symbols, no run pending
-                        // (kd_index_to_front inlined; the stretch's length comes from the ballot)
+                const u64 runm = __ballot((u32)lane < avail && mine < 2u);  // RUNA / RUNB
+                const u64 runb = __ballot((u32)lane < avail && mine == 1u); // RUNB
+                u32 q = 0;
+                while (q < avail && !done) {
+                    if ((runm >> q) & 1ull) {
+                        // a stretch of run symbols in closed form: symbol j of the stretch adds
+                        // (1 + s_j) * inc * 2^j, so the stretch adds inc * (2^k - 1 + its RUNB bits)
+                        const u64 rest = ~(runm >> q);
+                        const u32 nr = rest ? (u32)__builtin_ctzll(rest) : 64u; // <= avail - q: no run bits past avail
+                        const u32 take = min(nr, 20u);
+                        const u32 bits = (u32)(runb >> q) & ((1u << take) - 1u);
+                        const u64 r64 = (u64)rep + (u64)inc * (u64)(((1u << take) - 1u) + bits);
+                        q += take;
+                        if (r64 > 2u * 900000u + 2u) { status = KS_BLOCK_SIZE; done = true; break; }
+                        rep = (u32)r64;
+                        inc <<= take;
+                        continue;
+                    }
+                    const u32 sym = __builtin_amdgcn_readlane(mine, (int)q);
+                    if (sym & KD_SYM_ERR) { status = sym & 0xffu; done = true; break; }
+                    if (rep > 0) {
+                        // the pending run ends here
+                        if (len + rep > block_size) { status = KS_BLOCK_SIZE; done = true; break; }
+                        while (rep > 0) {
+                            const u32 lo = len & 63u, take = min(rep, 64u - lo);
+                            if ((u32)lane >= lo && (u32)lane < lo + take) pend = curbyte;
+                            len += take;
+                            rep -= take;
+                            if ((len & 63u) == 0) out[len - 64u + lane] = (u8)pend;
+                        }
+                        inc = 1;
+                    }
+                    if ((int)sym == eob) { done = true; break; }
+                    if (len + (avail - q) <= block_size) {
+                        // the common case: a stretch of plain MTF symbols (kd_index_to_front inlined;
+                        // the stretch's length comes from the ballot; q itself is plain)
                         const u64 rest = ~(plain >> q);
                         const u32 np = rest ? (u32)__builtin_ctzll(rest) : 64u;
                         const u32 qe = q + np; // <= avail: entries past avail are not plain
@@ -458,49 +513,39 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                             const u32 k2 = __builtin_amdgcn_readlane(pk, (int)q);
                             const int src = (int)(k2 & 255u);
                             const u32 sh = k2 >> 8;
-                            const u32 v = (__builtin_amdgcn_readlane(L, src) >> sh) & 255u;
-                            const u32 up = (u32)__builtin_amdgcn_update_dpp(0, (int)L, 0x138, 0xf, 0xf, false);
-                            const u32 shifted = (L << 8) | ((lane == 0) ? v : (up >> 24));
                             const u32 m = 0xffffffffu >> (24u - sh); // bytes 0..k of the source lane's word move
-                            const u32 at_src = (shifted & m) | (L & ~m);
-                            L = (lane < src) ? shifted : ((lane == src) ? at_src : L);
+                            u32 v;
+                            if (src == 0) {
+                                // one of the first four entries: scalar registers only
+                                v = (F >> sh) & 255u;
+                                F = (((F << 8) | v) & m) | (F & ~m);
+                                fdirty = true;
+                            } else {
+                                if (fdirty) { L = write_lane(L, F, 0); fdirty = false; }
+                                v = (__builtin_amdgcn_readlane(L, src) >> sh) & 255u;
+                                const u32 up = (u32)__builtin_amdgcn_update_dpp(0, (int)L, 0x138, 0xf, 0xf, false);
+                                const u32 shifted = (L << 8) | ((lane == 0) ? v : (up >> 24));
+                                const u32 at_src = (shifted & m) | (L & ~m);
+                                L = (lane < src) ? shifted : ((lane == src) ? at_src : L);
+                                F = (u32)__builtin_amdgcn_readlane((int)L, 0);
+                            }
                             curbyte = v;
-                            if ((u32)lane == (len & 63u)) pend = v;
+                            pend = write_lane(pend, v, (int)(len & 63u));
                             len++;
                             if ((len & 63u) == 0) out[len - 64u + lane] = (u8)pend;
                         }
-                        if (q >= avail) break;
-                    }
-                    const u32 sym = __builtin_amdgcn_readlane(mine, (int)q);
-                    if (sym & KD_SYM_ERR) { status = sym & 0xffu; done = true; break; }
-                    if (sym == 0) {
-                        rep += inc;
-                        inc <<= 1;
-                    } else if (sym == 1) {
-                        rep += inc << 1;
-                        inc <<= 1;
                     } else {
-                        if (rep > 0) {
-                            if (len + rep > block_size) { status = KS_BLOCK_SIZE; done = true; break; }
-                            while (rep > 0) {
-                                const u32 lo = len & 63u, take = min(rep, 64u - lo);
-                                if ((u32)lane >= lo && (u32)lane < lo + take) pend = curbyte;
-                                len += take;
-                                rep -= take;
-                                if ((len & 63u) == 0) out[len - 64u + lane] = (u8)pend;
-                            }
-                            inc = 1;
-                        }
-                        if ((int)sym == eob) { done = true; break; }
+                        // close to the block size: one symbol at a time, with the reference's check
                         if (len >= block_size) { status = KS_BLOCK_SIZE; done = true; break; }
+                        if (fdirty) { L = write_lane(L, F, 0); fdirty = false; }
                         curbyte = kd_index_to_front(L, (sym - 1u) & 255u);
+                        F = (u32)__builtin_amdgcn_readlane((int)L, 0);
                         // bytes gather in a register row (lane = position mod 64): one store per 64
-                        if ((u32)lane == (len & 63u)) pend = curbyte;
+                        pend = write_lane(pend, curbyte, (int)(len & 63u));
                         len++;
                         if ((len & 63u) == 0) out[len - 64u + lane] = (u8)pend;
+                        q++;
                     }
-                    if (rep > 2u * 900000u + 2u) { status = KS_BLOCK_SIZE; done = true; break; }
-                    room = len + (avail - q) <= block_size; // a run may have been written
                 }
                 tail += avail;
                 __hip_atomic_store(&s_tail, tail, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
