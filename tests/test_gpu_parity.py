@@ -528,3 +528,40 @@ def test_failed_allocation_leaves_the_context_usable():
         assert bz2.decompress(d_out[:k].cpu().numpy().tobytes()) == bytes(64 << 20)
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("shift", [1, 2, 3, 7, 13])
+def test_unaligned_device_input(ctx, orc, shift):
+    """K1 reads 16 input bytes per thread with one aligned load when it can: an input pointer that
+    is not 16-byte aligned takes the single-byte path of the scan and of the emit.  Runs of every
+    length class around tile and block boundaries (level 1: several blocks), against the oracle."""
+    import torch
+    rng = np.random.default_rng(100 + shift)
+    parts = [corpus.text(70000, 50 + shift), np.zeros(5000, dtype=np.uint8), corpus.segment("runs", 120000, shift),
+             np.full(260 * 255 + 3, 0x41, dtype=np.uint8), rng.integers(0, 256, 90001, dtype=np.uint8),
+             np.repeat(rng.integers(0, 256, 3000, dtype=np.uint8), rng.integers(1, 9, 3000))]
+    d = np.concatenate(parts)
+    want, _ = orc.compress(d, 1)
+    holder = torch.zeros(d.size + 64, dtype=torch.uint8, device="cuda")
+    view = holder[shift:shift + d.size]
+    view.copy_(torch.from_numpy(d))
+    assert view.data_ptr() % 16 == shift % 16
+    cap = ctx.L.bz2hip_compress_bound(d.size)
+    out = torch.empty(cap + 64, dtype=torch.uint8, device="cuda")
+    n = ctx.compress_device(view.data_ptr(), d.size, 1, out.data_ptr(), cap)
+    assert out[:n].cpu().numpy().tobytes() == want
+
+
+def test_block_starts_inside_long_runs(ctx, orc):
+    """Blocks that start inside runs longer than the 64-byte probe of the split (the run's end comes
+    from the cell records), runs that span tiles and blocks, and data that ends inside a run."""
+    rng = np.random.default_rng(9)
+    parts = []
+    for k in range(40):
+        parts.append(np.full(int(rng.integers(60, 70000)), int(rng.integers(0, 256)), dtype=np.uint8))
+        parts.append(rng.integers(0, 256, int(rng.integers(1, 9000)), dtype=np.uint8))
+    parts.append(np.full(300000, 7, dtype=np.uint8))
+    d = np.concatenate(parts)
+    for level in (1, 2):
+        want, nb = orc.compress(d, level)
+        assert ctx.compress(d, level) == want, level
