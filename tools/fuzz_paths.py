@@ -50,18 +50,18 @@ for seed in range(first, first + count):
             got += part
     elif mode == 1:    # tiny batch caps: many batches, both lanes
         got = ctx_for(int(rng.integers(1, 5))).compress(d, level)
-    elif mode == 2:    # sharded over 1..4 "ranks" run one after the other
+    elif mode == 2:    # sharded over 1..4 "ranks" run one after the other, the chain hop in a dict
+        from bzip2_amd._lib import stitch
         world = int(rng.integers(1, 5))
         c = ctx_for(0)
-        held = {}
-        got = None
-        for r in reversed(range(world)):
-            def gather(obj, r=r):
-                held[r] = obj
-                return [held[q] for q in range(world)] if r == 0 else None
-            out = parallel.compress_sharded(d, level, c, rank=r, world=world, gather=gather)
-            if r == 0:
-                got = out
+        hop, segs = {}, []
+        for r in range(world):
+            eng = parallel.GpuShardEngine(c, 0)
+            eng.bind(d)
+            segs.append(parallel.run_rank(eng, level, r, world, d.size, lambda r=r: hop[r],
+                                          lambda v, r=r: hop.__setitem__(r + 1, v),
+                                          lookahead=int(rng.integers(1000, 200000))))
+        got = stitch(level, segs)
     else:              # stage by stage: split, then whole-block compress of every block
         c = ctx_for(0)
         starts, rles, present, crc = c.rle1_split(d, level)
