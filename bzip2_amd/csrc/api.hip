@@ -124,7 +124,7 @@ static void wfree(bz2hip_ctx *c) {
     if (c->w_region) (void)hipFree(c->w_region);
     if (c->w_eregion) (void)hipFree(c->w_eregion);
     c->w_region = c->w_eregion = nullptr;
-    c->w_rs = c->w_P = c->w_agg1 = c->w_agg2 = c->w_starts = c->w_eagg = c->w_cagg = nullptr;
+    c->w_rs = c->w_P = c->w_agg1 = c->w_agg2 = c->w_starts = c->w_cagg = nullptr;
     c->w_P16 = nullptr;
     c->w_binfo = nullptr;
 }
@@ -151,11 +151,11 @@ static size_t layout_window(bz2hip_ctx *c, size_t wlen, u32 mb, u8 *base) {
     if (base) { c->w_rs = rs; c->w_P = P; c->w_P16 = p16; c->w_binfo = bi; c->w_agg1 = a1; c->w_agg2 = a2; c->w_starts = st; }
     return A.off;
 }
-// per-batch emit / CRC tile partials
+// per-batch CRC tile partials (the emit needs none since its tile offsets come from the scan)
 static size_t layout_emit(bz2hip_ctx *c, int nb, u32 ETPB, u8 *base) {
     Carver A{base};
-    u32 *e = A.get<u32>((size_t)nb * ETPB), *g = A.get<u32>((size_t)nb * ETPB);
-    if (base) { c->w_eagg = e; c->w_cagg = g; }
+    u32 *g = A.get<u32>((size_t)nb * ETPB);
+    if (base) c->w_cagg = g;
     return A.off;
 }
 
@@ -568,7 +568,7 @@ extern "C" int bz2hip_compress_device_noalloc(bz2hip_ctx *c, const void *d_in, s
         struct Saved {
             bz2hip_ctx *c;
             Batch batch;
-            u32 *w_rs, *w_P, *w_agg1, *w_agg2, *w_starts, *w_eagg, *w_cagg;
+            u32 *w_rs, *w_P, *w_agg1, *w_agg2, *w_starts, *w_cagg;
             u16 *w_P16;
             u32 *w_binfo;
             size_t w_cap;
@@ -577,7 +577,7 @@ extern "C" int bz2hip_compress_device_noalloc(bz2hip_ctx *c, const void *d_in, s
             bool profile;
             explicit Saved(bz2hip_ctx *cc)
                 : c(cc), batch(std::move(cc->batch)), w_rs(cc->w_rs), w_P(cc->w_P), w_agg1(cc->w_agg1),
-                  w_agg2(cc->w_agg2), w_starts(cc->w_starts), w_eagg(cc->w_eagg), w_cagg(cc->w_cagg),
+                  w_agg2(cc->w_agg2), w_starts(cc->w_starts), w_cagg(cc->w_cagg),
                   w_P16(cc->w_P16), w_binfo(cc->w_binfo), w_cap(cc->w_cap), w_maxblocks(cc->w_maxblocks), w_ETPB(cc->w_ETPB),
                   w_eagg_nb(cc->w_eagg_nb), profile(cc->profile) {
                 cc->batch = Batch();
@@ -587,7 +587,7 @@ extern "C" int bz2hip_compress_device_noalloc(bz2hip_ctx *c, const void *d_in, s
             ~Saved() {
                 c->batch = std::move(batch);
                 c->w_rs = w_rs; c->w_P = w_P; c->w_agg1 = w_agg1; c->w_agg2 = w_agg2;
-                c->w_starts = w_starts; c->w_eagg = w_eagg; c->w_cagg = w_cagg;
+                c->w_starts = w_starts; c->w_cagg = w_cagg;
                 c->w_P16 = w_P16;
                 c->w_binfo = w_binfo;
                 c->w_cap = w_cap; c->w_maxblocks = w_maxblocks; c->w_ETPB = w_ETPB;

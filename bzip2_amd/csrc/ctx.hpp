@@ -140,10 +140,10 @@ struct bz2hip_ctx {
     }
     // window scratch for K1 (split / RLE1 / CRC)
     u32 *w_rs = nullptr, *w_P = nullptr, *w_agg1 = nullptr, *w_agg2 = nullptr;
-    u32 *w_starts = nullptr, *w_eagg = nullptr;
+    u32 *w_starts = nullptr;
     u32 *w_binfo = nullptr;  // per block: end of its first run, P just after it (k1_split -> k1_emit)
     u16 *w_P16 = nullptr;    // flushed-length prefix per input byte, tile-local (k1_rle1.hip)
-    u32 *w_cagg = nullptr;   // CRC tile partials (same shape as w_eagg; used on the other stream)
+    u32 *w_cagg = nullptr;   // CRC tile partials [batch blocks][w_ETPB] (used on the other stream)
     void *w_region = nullptr;  // device region holding rs / P / aggregates / starts
     void *w_eregion = nullptr; // device region holding the emit / CRC tile partials
     // tuning knobs, read from the environment once in bz2hip_create (experiments only)

@@ -207,11 +207,7 @@ __global__ void k1_sentinels(u32 *Hc, u32 *Pc, u16 *P16, u32 *agg_c, const u32 *
     }
 }
 
-// accessors for the two searched arrays
-struct PlainArr {
-    const u32 *a;
-    __device__ __forceinline__ u32 operator()(u32 i) const { return a[i]; }
-};
+// accessor of the searched prefix array
 struct PrefixArr { // absolute flushed-length prefix = tile-local value (16 bits) + scanned tile sum
     const u16 *P;
     const u32 *agg;
@@ -285,10 +281,6 @@ struct CellArrs {
     const u32 *Hc, *Pc, *agg;
     u32 n;
 };
-struct CellStartP { // P at the first byte of a cell (non-decreasing in the cell index)
-    const u32 *Pc, *agg;
-    __device__ __forceinline__ u32 operator()(u32 c) const { return Pc[c] + agg[c / K1_CPT]; }
-};
 struct CellHeadArr { // last head (+1) before a cell
     const u32 *Hc;
     __device__ __forceinline__ u32 operator()(u32 c) const { return Hc[c]; }
@@ -340,26 +332,6 @@ __device__ __forceinline__ void cell_compute(const CellArrs &A, u32 c, const Cel
         run += (u32)__builtin_amdgcn_readlane((int)inc, 63);
         if (m) carry = rowbase + (63 - __clzll((unsigned long long)m)) + 1;
     }
-}
-// P(x) out of a computed cell (x inside it)
-__device__ __forceinline__ u32 cell_P_at(const u32 (&pv)[4], u32 x) {
-    const u32 r = (x % K1_CELL) / 64, l = x % 64;
-    u32 v = pv[0];
-    if (r == 1) v = pv[1];
-    if (r == 2) v = pv[2];
-    if (r == 3) v = pv[3];
-    return __shfl(v, l, 64);
-}
-// first position i of the cell with P(i) > thr and i <= upto; ~0 if none
-__device__ __forceinline__ u32 cell_first_gt(const u32 (&pv)[4], u32 c, u32 thr, u32 upto) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const u32 i = c * K1_CELL + r * 64 + lane;
-        const u64 m = __ballot(i <= upto && pv[r] > thr);
-        if (m) return c * K1_CELL + r * 64 + (u32)(__ffsll((unsigned long long)m) - 1);
-    }
-    return 0xffffffffu;
 }
 // first head position > s inside cell c (heads of computed rows); ~0 if none
 __device__ __forceinline__ u32 cell_first_head_after(const u64 (&hm)[4], u32 c, u32 s) {
