@@ -144,6 +144,12 @@ struct KdBits {
 #define KD_RING 2048        // symbols between the two waves of kd_huff
 #define KD_SPIN_MAX (1 << 22)
 #define KD_SYM_ERR 0x8000u  // ring entry: the producer stopped with status (entry & 0xff)
+// The ring, its head and its tail live in LDS, and the LDS serves one wave's operations in order:
+// "ring entries, then head" (and "ring reads, then tail") needs no more than that the compiler
+// keeps the order and that the wave's own LDS operations have been issued.  An acquire / release
+// at workgroup scope would also wait for the wave's outstanding GLOBAL accesses (the consumer's row
+// stores: a memory round trip per batch of 64 symbols).
+#define KD_LDS_ORDER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 // Two waves per block.  Wave 0 parses the header and builds the tables, then only decodes Huffman
 // symbols into an LDS ring; wave 1 turns symbols into BWT bytes (runs, inverse MTF).  The two serial
@@ -417,7 +423,8 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                     // ring full: wait for the consumer (or for its abort)
                     u32 spins = 0;
                     for (;;) {
-                        tail_seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_tail, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+                        tail_seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                        KD_LDS_ORDER();
                         if (head + cnt - tail_seen <= KD_RING) break;
                         if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) ||
                             ++spins > KD_SPIN_MAX) { stop = 2; break; }
@@ -434,7 +441,8 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                 head += cnt;
                 if (head - published >= 32u || stop) {
                     published = head;
-                    __hip_atomic_store(&s_head, head, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    KD_LDS_ORDER();
+                    __hip_atomic_store(&s_head, head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
             if (lane == 0) {
@@ -457,7 +465,8 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                 // wait for symbols
                 u32 head, spins = 0;
                 for (;;) {
-                    head = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_head, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    head = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    KD_LDS_ORDER();
                     if (head != tail) break;
                     if (++spins > KD_SPIN_MAX) { status = KS_DECODE; done = true; break; }
                     __builtin_amdgcn_s_sleep(1);
@@ -548,7 +557,8 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                     }
                 }
                 tail += avail;
-                __hip_atomic_store(&s_tail, tail, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                KD_LDS_ORDER();
+                __hip_atomic_store(&s_tail, tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             if ((u32)lane < (len & 63u)) out[(len & ~63u) + lane] = (u8)pend; // the last, partial row
             if (lane == 0) {
