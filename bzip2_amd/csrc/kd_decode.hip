@@ -318,12 +318,25 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
             // window go to the ring in one store.
             const int nsel = __builtin_amdgcn_readfirstlane((int)s_nsel);
             u32 head = 0, tail_seen = 0, published = 0;
-            const u64 wsafe = nbytes / 4u, nbits = nbytes * 8u;
+            const u64 nbits = nbytes * 8u;
             int gleft = 0, gidx = -1, cur = sel[0];
             u32 stop = 0; // 0: running, 1: the final ring entry is among those being written, 2: gave up
+            // From here on the reader is one number: bp, the next symbol's bit offset inside the LDS
+            // window (which starts at stream word wbase).  Every lane fetches the 32 bits at offset
+            // bp + lane straight from the window -- no scalar bit buffer to shift and refill, which
+            // was a third of the loop's instructions.
+            u64 wbase;
+            u32 bp;
+            {
+                const u64 cons = br.consumed();
+                wbase = KdBits::uni64(cons >> 5);
+                bp = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(cons & 31u));
+                br.load_window(wbase);
+            }
             while (!stop) {
                 // wave-uniform state in scalar registers (see KdBits::pin)
-                br.pin();
+                wbase = KdBits::uni64(wbase);
+                bp = (u32)__builtin_amdgcn_readfirstlane((int)bp);
                 gleft = __builtin_amdgcn_readfirstlane(gleft);
                 gidx = __builtin_amdgcn_readfirstlane(gidx);
                 cur = __builtin_amdgcn_readfirstlane(cur);
@@ -343,50 +356,61 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                     }
                 }
                 if (!stop) {
-                    br.fill();
-                    const int usable = 63; // every lane's offset has 10 valid bits (97 are buffered)
-                    const u64 fld = lane ? ((br.hi << lane) | (br.lo >> (64 - lane))) : br.hi;
-                    const u32 myent = lut[cur][(u32)(fld >> (64 - KD_LUT_BITS))];
-                    const bool nearend = br.wpos > wsafe;
-                    int off = 0;
+                    // the lanes read the bits [bp, bp + 63 + 32) and one word more
+                    if (bp + 160u > KD_WIN * 8u) {
+                        wbase += bp >> 5;
+                        bp &= 31u;
+                        br.load_window(wbase);
+                    }
+                    const u32 a = bp + (u32)lane;
+                    const u32 d0 = __builtin_bswap32(win[a >> 5]), d1 = __builtin_bswap32(win[(a >> 5) + 1]);
+                    const u32 fld = (u32)((((u64)d0 << 32) | (u64)d1) >> (32u - (a & 31u))); // 32 bits at offset a
+                    const u32 myent = lut[cur][fld >> (32 - KD_LUT_BITS)];
+                    const u64 here = wbase * 32u + (u64)bp; // stream bit of the next symbol
+                    // (no bit past the end can be used by this step while 128 more bits exist)
+                    const bool nearend = here + 128u > nbits;
+                    u32 off = 0;
                     if (!nearend) {
-                        // entries the scalar chain stops at: no entry, no symbol, end of block
+                        // entries the scalar chain stops at: no entry, no symbol, end of block; the
+                        // chain follows the next offset stored in the entry (bits 16..22) and ends after
+                        // the entry whose successor lies outside the 64 offsets (bit 23)
                         const u32 sy = myent >> 5;
-                        const u32 ment = myent | ((myent == 0 || sy == 511u || (int)sy == eob) ? 0x8000u : 0u);
-                        int n = 0;
-                        while (n < gleft && off <= usable) {
-                            const u32 e = __builtin_amdgcn_readlane(ment, off);
+                        const u32 nx = (u32)lane + (myent & 31u);
+                        const u32 ment = (myent & 0xffffu) | (nx << 16) | (nx > 63u ? 0x800000u : 0u) |
+                                         ((myent == 0 || sy == 511u || (int)sy == eob) ? 0x8000u : 0u);
+                        u32 n = 0, e;
+                        do {
+                            e = __builtin_amdgcn_readlane(ment, (int)off);
                             if (e & 0x8000u) break;
                             visited |= 1ull << off;
-                            off += (int)(e & 31u);
+                            off = (e >> 16) & 127u;
                             n++;
-                        }
+                        } while (!(e & 0x800000u) && n < (u32)gleft);
                         if (n > 0) {
                             // the lanes whose offset the chain visited hold its symbols, in order
                             fast = true;
-                            gleft -= n;
-                            cnt = (u32)n;
+                            gleft -= (int)n;
+                            cnt = n;
                             mysym = sy;
                         } else {
-                            const u32 e = __builtin_amdgcn_readlane(myent, 0);
-                            if (e != 0) { // no symbol for this code, or the end of the block
-                                off = (int)(e & 31u);
+                            const u32 e0 = __builtin_amdgcn_readlane(myent, 0);
+                            if (e0 != 0) { // no symbol for this code, or the end of the block
+                                off = e0 & 31u;
                                 gleft--;
-                                mysym = ((e >> 5) == 511u) ? (KD_SYM_ERR | KS_DECODE) : (e >> 5);
+                                mysym = ((e0 >> 5) == 511u) ? (KD_SYM_ERR | KS_DECODE) : (e0 >> 5);
                                 cnt = 1;
                                 stop = 1;
                             }
                         }
                     } else {
-                        // the last words of the stream: test every symbol for the end of the data
-                        while (gleft > 0 && off <= usable) {
-                            const u32 e = __builtin_amdgcn_readlane(myent, off);
+                        // the last bits of the stream: test every symbol for the end of the data
+                        while (gleft > 0 && off <= 63u) {
+                            const u32 e = __builtin_amdgcn_readlane(myent, (int)off);
                             if (e == 0) break; // longer than 10 bits (or a table the block does not define)
-                            off += (int)(e & 31u);
+                            off += e & 31u;
                             gleft--;
                             u32 entry = e >> 5;
-                            // (no bit past the end can have been used while wpos * 32 <= the stream's bits)
-                            if (br.wpos * 32u - (u64)(br.bc - off) > nbits) { entry = KD_SYM_ERR | KS_INSUFFICIENT; stop = 1; }
+                            if (here + off > nbits) { entry = KD_SYM_ERR | KS_INSUFFICIENT; stop = 1; }
                             else if (entry == 511u) { entry = KD_SYM_ERR | KS_DECODE; stop = 1; }
                             else if ((int)entry == eob) stop = 1;
                             if ((u32)lane == cnt) mysym = entry;
@@ -394,14 +418,16 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                             if (stop) break;
                         }
                     }
-                    br.skip(off);
+                    bp += off;
                     if (cnt == 0) {
-                        // walk the limits for this one symbol
+                        // walk the limits for this one symbol: the 32 bits at bp are lane 0's field
+                        // (nothing was consumed in this step)
+                        const u32 f0 = __builtin_amdgcn_readlane(fld, 0);
                         gleft--;
                         int sym = -1;
                         int cl = __builtin_amdgcn_readfirstlane(minlen[cur]);
                         while (cl <= KD_MAXLEN) {
-                            const int code = (int)br.peek(cl);
+                            const int code = cl ? (int)(f0 >> (32 - cl)) : 0;
                             if (code <= __builtin_amdgcn_readfirstlane(limits[cur][cl])) {
                                 const int ix = code - __builtin_amdgcn_readfirstlane(bases[cur][cl]);
                                 if (ix >= 0 && ix < MAX_ALPHA) sym = __builtin_amdgcn_readfirstlane((int)symbols[cur][ix]);
@@ -409,8 +435,8 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                             }
                             cl++;
                         }
-                        br.skip(min(cl, KD_MAXLEN + 1));
-                        if (nearend && br.over()) { mysym = KD_SYM_ERR | KS_INSUFFICIENT; stop = 1; }
+                        bp += (u32)min(cl, KD_MAXLEN + 1);
+                        if (nearend && wbase * 32u + (u64)bp > nbits) { mysym = KD_SYM_ERR | KS_INSUFFICIENT; stop = 1; }
                         else if (sym < 0) { mysym = KD_SYM_ERR | KS_DECODE; stop = 1; }
                         else {
                             mysym = (u32)sym;
@@ -446,7 +472,7 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                 }
             }
             if (lane == 0) {
-                const u64 e = br.consumed();
+                const u64 e = wbase * 32u + (u64)bp;
                 s_end_lo = (u32)e;
                 s_end_hi = (u32)(e >> 32);
             }
@@ -454,10 +480,6 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
             // ---- consumer: symbols -> BWT bytes, S/BZip2BlockDecompressor.swift:266-321.  The MTF
             // list holds the bytes themselves (the symbol map applied to the identity list).
             u32 L = ((const u32 *)symmap)[lane];
-            // F = the list's first four entries (lane 0's word) in a scalar register; while fdirty,
-            // F is ahead of lane 0 of L
-            u32 F = (u32)__builtin_amdgcn_readlane((int)L, 0);
-            bool fdirty = false;
             u32 rep = 0, inc = 1, curbyte = symmap[0], len = 0, pend = 0;
             u32 tail = 0, status = KS_OK;
             bool done = false;
@@ -479,6 +501,7 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                 const u64 plain = __ballot(mine >= 2u && mine < KD_SYM_ERR && (int)mine != eob);
                 const u32 pq = (mine - 1u) & 255u;
                 const u32 pk = (pq >> 2) | ((pq & 3u) << 11); // lane | byte shift << 8
+                const u64 front = plain & __ballot(pq < 4u);  // plain symbols among the first four entries
                 const u64 runm = __ballot((u32)lane < avail && mine < 2u);  // RUNA / RUNB
                 const u64 runb = __ballot((u32)lane < avail && mine == 1u); // RUNB
                 u32 q = 0;
@@ -518,37 +541,59 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                         const u64 rest = ~(plain >> q);
                         const u32 np = rest ? (u32)__builtin_ctzll(rest) : 64u;
                         const u32 qe = q + np; // <= avail: entries past avail are not plain
-                        for (; q < qe; q++) {
-                            const u32 k2 = __builtin_amdgcn_readlane(pk, (int)q);
-                            const int src = (int)(k2 & 255u);
-                            const u32 sh = k2 >> 8;
-                            const u32 m = 0xffffffffu >> (24u - sh); // bytes 0..k of the source lane's word move
-                            u32 v;
-                            if (src == 0) {
-                                // one of the first four entries: scalar registers only
-                                v = (F >> sh) & 255u;
-                                F = (((F << 8) | v) & m) | (F & ~m);
-                                fdirty = true;
-                            } else {
-                                if (fdirty) { L = write_lane(L, F, 0); fdirty = false; }
-                                v = (__builtin_amdgcn_readlane(L, src) >> sh) & 255u;
-                                const u32 up = (u32)__builtin_amdgcn_update_dpp(0, (int)L, 0x138, 0xf, 0xf, false);
-                                const u32 shifted = (L << 8) | ((lane == 0) ? v : (up >> 24));
-                                const u32 at_src = (shifted & m) | (L & ~m);
-                                L = (lane < src) ? shifted : ((lane == src) ? at_src : L);
-                                F = (u32)__builtin_amdgcn_readlane((int)L, 0);
+                        // A lone wave issues one instruction every 6.5-10 cycles,
+                        // so the stretch is cut into pieces that need no test per symbol: at the rows
+                        // of 64 output bytes (one store per row), and into runs of symbols that hit
+                        // the first four list entries (a scalar register holds them for the run: no
+                        // vector instruction but the byte's placement) and runs of symbols that do not.
+                        while (q < qe) {
+                            const u32 lo = len & 63u;
+                            const u32 cnt = min(qe - q, 64u - lo);
+                            const u32 qrow = q + cnt;
+                            u32 at = lo; // lane of the next output byte
+                            while (q < qrow) {
+                                const bool isfront = (front >> q) & 1ull;
+                                const u64 same = isfront ? ~(front >> q) : (front >> q);
+                                const u32 k = min(same ? (u32)__builtin_ctzll(same) : 64u, qrow - q);
+                                const u32 qk = q + k;
+                                if (isfront) {
+                                    u32 F = (u32)__builtin_amdgcn_readlane((int)L, 0);
+                                    u32 v = 0;
+                                    for (; q < qk; q++, at++) {
+                                        const u32 sh = __builtin_amdgcn_readlane(pk, (int)q) >> 8;
+                                        const u32 m = 0xffffffffu >> (24u - sh); // bytes 0..k move
+                                        v = (F >> sh) & 255u;
+                                        F = (((F << 8) | v) & m) | (F & ~m);
+                                        pend = write_lane(pend, v, (int)at);
+                                    }
+                                    curbyte = v;
+                                    L = write_lane(L, F, 0);
+                                } else {
+                                    u32 v = 0;
+                                    for (; q < qk; q++, at++) {
+                                        const u32 k2 = __builtin_amdgcn_readlane(pk, (int)q);
+                                        const int src = (int)(k2 & 255u);
+                                        const u32 sh = k2 >> 8;
+                                        const u32 m = 0xffffffffu >> (24u - sh);
+                                        v = (__builtin_amdgcn_readlane(L, src) >> sh) & 255u;
+                                        // every word takes the top byte of the word before it, the first
+                                        // one v (wave_shr leaves lane 0 with the `old` operand)
+                                        const u32 up = (u32)__builtin_amdgcn_update_dpp((int)(v << 24), (int)L, 0x138, 0xf, 0xf, false);
+                                        const u32 shifted = __builtin_amdgcn_alignbit(L, up, 24); // (L << 8) | (up >> 24)
+                                        const u32 at_src = (shifted & m) | (L & ~m);
+                                        L = (lane < src) ? shifted : ((lane == src) ? at_src : L);
+                                        pend = write_lane(pend, v, (int)at);
+                                    }
+                                    curbyte = v;
+                                }
                             }
-                            curbyte = v;
-                            pend = write_lane(pend, v, (int)(len & 63u));
-                            len++;
+                            len += cnt;
                             if ((len & 63u) == 0) out[len - 64u + lane] = (u8)pend;
                         }
                     } else {
                         // close to the block size: one symbol at a time, with the reference's check
                         if (len >= block_size) { status = KS_BLOCK_SIZE; done = true; break; }
-                        if (fdirty) { L = write_lane(L, F, 0); fdirty = false; }
                         curbyte = kd_index_to_front(L, (sym - 1u) & 255u);
-                        F = (u32)__builtin_amdgcn_readlane((int)L, 0);
                         // bytes gather in a register row (lane = position mod 64): one store per 64
                         pend = write_lane(pend, curbyte, (int)(len & 63u));
                         len++;
