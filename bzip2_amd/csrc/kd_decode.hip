@@ -57,24 +57,6 @@ __global__ __launch_bounds__(256) void kd_scan_magic(const u8 *__restrict__ in, 
 }
 
 // ------------------------------------------------------------------ Huffman + MTF stage
-// MoveToFront.indexToFront on the wave-distributed list (4 entries per lane): the entry at
-// position p goes to the front; returns it
-__device__ __forceinline__ u32 kd_index_to_front(u32 &L, u32 p) {
-    const int lane = lane_id();
-    const int src = (int)(p >> 2);
-    const u32 k = p & 3u;
-    const u32 w = __builtin_amdgcn_readlane(L, src);
-    const u32 v = (w >> (8u * k)) & 255u;
-    // branch-free; for p = 0 the list comes out unchanged
-    const u32 up = (u32)__builtin_amdgcn_update_dpp(0, (int)L, 0x138, 0xf, 0xf, false); // wave_shr:1
-    const u32 carry = (lane == 0) ? v : (up >> 24);
-    const u32 shifted = (L << 8) | carry;
-    const u32 keep = (k == 3) ? 0u : (0xffffffffu << (8u * (k + 1u)));
-    const u32 at_src = (shifted & ~keep) | (L & keep);
-    L = (lane < src) ? shifted : ((lane == src) ? at_src : L);
-    return v;
-}
-
 // MSB-first bit reader over an LDS window of the stream, refilled 32 bits at a time (window words
 // are aligned to stream offsets that are multiples of 4, whatever the pointer's alignment)
 struct KdBits {
@@ -479,10 +461,20 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
         } else {
             // ---- consumer: symbols -> BWT bytes, S/BZip2BlockDecompressor.swift:266-321.  The MTF
             // list holds the bytes themselves (the symbol map applied to the identity list).
+            // A batch of up to 64 ring entries is handled in the vector domain (lane = entry) except
+            // for the one thing that is serial, the list: what every entry emits (a plain symbol 1
+            // byte, the j-th symbol of a run stretch (1 + RUNB) << j copies of the current byte -- all
+            // bytes of a stretch are equal, so each run symbol writes its own share), the output
+            // offsets (a wave scan), the reference's size checks (they are monotone in those prefix
+            // sums: the first lane that violates one is where the reference stops) and the stores.
+            // The serial loop only moves list entries: a lone wave issues one instruction every
+            // 6.5-10 cycles, so instructions per symbol are what counts.
             u32 L = ((const u32 *)symmap)[lane];
-            u32 rep = 0, inc = 1, curbyte = symmap[0], len = 0, pend = 0;
+            u32 curbyte = symmap[0], len = 0;
+            u32 runk = 0, runrep = 0; // an open run stretch: symbols so far, length so far
             u32 tail = 0, status = KS_OK;
             bool done = false;
+            const u64 lt = (1ull << lane) - 1ull;
             while (!done) {
                 // wait for symbols
                 u32 head, spins = 0;
@@ -495,117 +487,115 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                 }
                 if (done) break;
                 const u32 avail = min(head - tail, 64u);
-                const u32 mine = ((u32)lane < avail) ? ring[(tail + lane) % KD_RING] : 0u;
-                // per batch, in the vector domain: which entries are plain MTF symbols, and their list
-                // position split into (lane, byte shift), so that the serial part below is short
-                const u64 plain = __ballot(mine >= 2u && mine < KD_SYM_ERR && (int)mine != eob);
+                const bool valid = (u32)lane < avail;
+                const u32 mine = valid ? ring[(tail + lane) % KD_RING] : 0u;
+                const bool iserr = valid && (mine & KD_SYM_ERR);
+                const bool isrun = valid && mine < 2u;
+                const bool iseob = valid && !iserr && (int)mine == eob;
+                const bool isplain = valid && !isrun && !iserr && !iseob;
+                const u64 runm = __ballot(isrun), plainm = __ballot(isplain);
+                const u64 nonrun = __ballot(valid && !isrun);
+                // run symbols: exponent = index inside the stretch (a stretch may come over from the
+                // batch before), share = (1 + RUNB) << exponent, saturated (2^22 is already too long)
+                const u64 nrb = nonrun & lt;
+                const int lastnr = nrb ? 63 - __clzll((unsigned long long)nrb) : -1;
+                const u32 expo = (u32)(lane - lastnr - 1) + (lastnr < 0 ? runk : 0u);
+                const u32 share = isrun ? (expo < 21u ? (1u + mine) << expo : (1u << 22)) : 0u;
+                const u32 e = isrun ? share : (isplain ? 1u : 0u);
+                const u32 inc = wave_incl_scan_add(e);
+                const u32 E = inc - e; // bytes the batch emits before this entry
+                // length of the stretch up to and including this run symbol (S/BZip2BlockDecompressor.swift:
+                // 286-297 checks it symbol by symbol)
+                const u32 Ea = lastnr < 0 ? 0u : (u32)__shfl((int)inc, lastnr < 0 ? 0 : lastnr, 64);
+                const u32 R = inc - Ea + (lastnr < 0 ? runrep : 0u);
+                // the reference's stops, in its order at one symbol: error entry; run too long; a run
+                // that ends here does not fit; end of block; no room for this symbol
+                const bool afterrun = lane == 0 ? runk > 0 : ((runm >> (lane - 1)) & 1ull);
+                u32 st = KS_OK;
+                if (iserr) st = mine & 0xffu;
+                else if (isrun) { if (R > 2u * 900000u + 2u) st = KS_BLOCK_SIZE; }
+                else if (valid) {
+                    if (afterrun && len + E > block_size) st = KS_BLOCK_SIZE;
+                    else if (isplain && len + E >= block_size) st = KS_BLOCK_SIZE;
+                }
+                const u64 stopm = __ballot(st != KS_OK || iseob);
+                const u32 fstop = stopm ? (u32)__builtin_ctzll(stopm) : 64u; // entries before it are processed
+                const u64 live = fstop >= 64u ? ~0ull : ((1ull << fstop) - 1ull);
+                // ---- the list: plain symbols in order; vals = the byte of every plain entry
                 const u32 pq = (mine - 1u) & 255u;
                 const u32 pk = (pq >> 2) | ((pq & 3u) << 11); // lane | byte shift << 8
-                const u64 front = plain & __ballot(pq < 4u);  // plain symbols among the first four entries
-                const u64 runm = __ballot((u32)lane < avail && mine < 2u);  // RUNA / RUNB
-                const u64 runb = __ballot((u32)lane < avail && mine == 1u); // RUNB
-                u32 q = 0;
-                while (q < avail && !done) {
-                    if ((runm >> q) & 1ull) {
-                        // a stretch of run symbols in closed form: symbol j of the stretch adds
-                        // (1 + s_j) * inc * 2^j, so the stretch adds inc * (2^k - 1 + its RUNB bits)
-                        const u64 rest = ~(runm >> q);
-                        const u32 nr = rest ? (u32)__builtin_ctzll(rest) : 64u; // <= avail - q: no run bits past avail
-                        const u32 take = min(nr, 20u);
-                        const u32 bits = (u32)(runb >> q) & ((1u << take) - 1u);
-                        const u64 r64 = (u64)rep + (u64)inc * (u64)(((1u << take) - 1u) + bits);
-                        q += take;
-                        if (r64 > 2u * 900000u + 2u) { status = KS_BLOCK_SIZE; done = true; break; }
-                        rep = (u32)r64;
-                        inc <<= take;
-                        continue;
-                    }
-                    const u32 sym = __builtin_amdgcn_readlane(mine, (int)q);
-                    if (sym & KD_SYM_ERR) { status = sym & 0xffu; done = true; break; }
-                    if (rep > 0) {
-                        // the pending run ends here
-                        if (len + rep > block_size) { status = KS_BLOCK_SIZE; done = true; break; }
-                        while (rep > 0) {
-                            const u32 lo = len & 63u, take = min(rep, 64u - lo);
-                            if ((u32)lane >= lo && (u32)lane < lo + take) pend = curbyte;
-                            len += take;
-                            rep -= take;
-                            if ((len & 63u) == 0) out[len - 64u + lane] = (u8)pend;
-                        }
-                        inc = 1;
-                    }
-                    if ((int)sym == eob) { done = true; break; }
-                    if (len + (avail - q) <= block_size) {
-                        // the common case: a stretch of plain MTF symbols (kd_index_to_front inlined;
-                        // the stretch's length comes from the ballot; q itself is plain)
-                        const u64 rest = ~(plain >> q);
-                        const u32 np = rest ? (u32)__builtin_ctzll(rest) : 64u;
-                        const u32 qe = q + np; // <= avail: entries past avail are not plain
-                        // A lone wave issues one instruction every 6.5-10 cycles,
-                        // so the stretch is cut into pieces that need no test per symbol: at the rows
-                        // of 64 output bytes (one store per row), and into runs of symbols that hit
-                        // the first four list entries (a scalar register holds them for the run: no
-                        // vector instruction but the byte's placement) and runs of symbols that do not.
-                        while (q < qe) {
-                            const u32 lo = len & 63u;
-                            const u32 cnt = min(qe - q, 64u - lo);
-                            const u32 qrow = q + cnt;
-                            u32 at = lo; // lane of the next output byte
-                            while (q < qrow) {
-                                const bool isfront = (front >> q) & 1ull;
-                                const u64 same = isfront ? ~(front >> q) : (front >> q);
-                                const u32 k = min(same ? (u32)__builtin_ctzll(same) : 64u, qrow - q);
-                                const u32 qk = q + k;
-                                if (isfront) {
-                                    u32 F = (u32)__builtin_amdgcn_readlane((int)L, 0);
-                                    u32 v = 0;
-                                    for (; q < qk; q++, at++) {
-                                        const u32 sh = __builtin_amdgcn_readlane(pk, (int)q) >> 8;
-                                        const u32 m = 0xffffffffu >> (24u - sh); // bytes 0..k move
-                                        v = (F >> sh) & 255u;
-                                        F = (((F << 8) | v) & m) | (F & ~m);
-                                        pend = write_lane(pend, v, (int)at);
-                                    }
-                                    curbyte = v;
-                                    L = write_lane(L, F, 0);
-                                } else {
-                                    u32 v = 0;
-                                    for (; q < qk; q++, at++) {
-                                        const u32 k2 = __builtin_amdgcn_readlane(pk, (int)q);
-                                        const int src = (int)(k2 & 255u);
-                                        const u32 sh = k2 >> 8;
-                                        const u32 m = 0xffffffffu >> (24u - sh);
-                                        v = (__builtin_amdgcn_readlane(L, src) >> sh) & 255u;
-                                        // every word takes the top byte of the word before it, the first
-                                        // one v (wave_shr leaves lane 0 with the `old` operand)
-                                        const u32 up = (u32)__builtin_amdgcn_update_dpp((int)(v << 24), (int)L, 0x138, 0xf, 0xf, false);
-                                        const u32 shifted = __builtin_amdgcn_alignbit(L, up, 24); // (L << 8) | (up >> 24)
-                                        const u32 at_src = (shifted & m) | (L & ~m);
-                                        L = (lane < src) ? shifted : ((lane == src) ? at_src : L);
-                                        pend = write_lane(pend, v, (int)at);
-                                    }
-                                    curbyte = v;
-                                }
-                            }
-                            len += cnt;
-                            if ((len & 63u) == 0) out[len - 64u + lane] = (u8)pend;
-                        }
+                u32 vals = 0;
+                u64 pm = plainm & live;
+                u32 lastv = curbyte;
+                while (pm) {
+                    const int q = __builtin_ctzll(pm);
+                    asm("s_bitset0_b64 %0, %1" : "+s"(pm) : "s"(q));
+                    const u32 k2 = __builtin_amdgcn_readlane(pk, q);
+                    const int src = (int)(k2 & 255u);
+                    const u32 sh = k2 >> 8;
+                    const u32 m = 0xffffffffu >> (24u - sh); // bytes 0..k of the source lane's word move
+                    u32 v;
+                    if (src == 0) {
+                        // one of the first four entries: lane 0's word in scalar arithmetic
+                        u32 F = (u32)__builtin_amdgcn_readlane((int)L, 0);
+                        v = (F >> sh) & 255u;
+                        F = (((F << 8) | v) & m) | (F & ~m);
+                        L = write_lane(L, F, 0);
                     } else {
-                        // close to the block size: one symbol at a time, with the reference's check
-                        if (len >= block_size) { status = KS_BLOCK_SIZE; done = true; break; }
-                        curbyte = kd_index_to_front(L, (sym - 1u) & 255u);
-                        // bytes gather in a register row (lane = position mod 64): one store per 64
-                        pend = write_lane(pend, curbyte, (int)(len & 63u));
-                        len++;
-                        if ((len & 63u) == 0) out[len - 64u + lane] = (u8)pend;
-                        q++;
+                        v = (__builtin_amdgcn_readlane(L, src) >> sh) & 255u;
+                        // every word takes the top byte of the word before it, the first one v
+                        // (wave_shr leaves lane 0 with the `old` operand)
+                        const u32 up = (u32)__builtin_amdgcn_update_dpp((int)(v << 24), (int)L, 0x138, 0xf, 0xf, false);
+                        const u32 shifted = __builtin_amdgcn_alignbit(L, up, 24); // (L << 8) | (up >> 24)
+                        const u32 at_src = (shifted & m) | (L & ~m);
+                        L = (lane < src) ? shifted : ((lane == src) ? at_src : L);
                     }
+                    vals = write_lane(vals, v, q);
+                    lastv = v;
+                }
+                // ---- bytes out: a run symbol repeats the byte of the nearest plain entry before it
+                const u64 pb = plainm & live & lt;
+                const int psrc = pb ? 63 - __clzll((unsigned long long)pb) : 0;
+                const u32 prevv = (u32)__shfl((int)vals, psrc, 64);
+                const u32 byte = isplain ? vals : (pb ? prevv : curbyte);
+                const bool act = (live >> lane) & 1ull;
+                const u32 o = len + E;
+                const u32 cnt = act ? min(e, o < block_size ? block_size - o : 0u) : 0u; // never past the slot
+                // short shares by their own lane, long ones (> 64 bytes) by the whole wave
+                const u32 small = cnt <= 64u ? cnt : 0u;
+                const u32 maxs = wave_reduce_max(small);
+                for (u32 r = 0; r < maxs; r++)
+                    if (r < small) out[o + r] = (u8)byte;
+                u64 big = __ballot(cnt > 64u);
+                while (big) {
+                    const int q = __builtin_ctzll(big);
+                    big &= big - 1ull;
+                    const u32 bo = __builtin_amdgcn_readlane(o, q), bc = __builtin_amdgcn_readlane(cnt, q);
+                    const u32 bv = __builtin_amdgcn_readlane(byte, q);
+                    for (u32 r = (u32)lane; r < bc; r += 64u) out[bo + r] = (u8)bv;
+                }
+                // ---- state for the next batch
+                const u32 nproc = min(fstop, avail);
+                if (nproc > 0) {
+                    len += __builtin_amdgcn_readlane(inc, (int)nproc - 1);
+                    curbyte = lastv;
+                    if ((runm >> (nproc - 1)) & 1ull) {
+                        runk = __builtin_amdgcn_readlane(expo, (int)nproc - 1) + 1u;
+                        runrep = __builtin_amdgcn_readlane(R, (int)nproc - 1);
+                    } else {
+                        runk = 0;
+                        runrep = 0;
+                    }
+                }
+                if (fstop < avail) {
+                    // stopped inside the batch: an error, or the end of the block
+                    status = __builtin_amdgcn_readlane(st, (int)fstop);
+                    done = true;
                 }
                 tail += avail;
                 KD_LDS_ORDER();
                 __hip_atomic_store(&s_tail, tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            if ((u32)lane < (len & 63u)) out[(len & ~63u) + lane] = (u8)pend; // the last, partial row
             if (lane == 0) {
                 s_len = len;
                 s_status = status;
