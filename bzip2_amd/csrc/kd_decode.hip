@@ -139,7 +139,8 @@ struct KdBits {
 // first one in the reference's order wins; a wave that gives up raises s_abort for the other.
 __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nbytes,
                                                const u64 *__restrict__ cand, u32 block_size, u32 S,
-                                               u8 *__restrict__ bwt, u32 *__restrict__ meta) {
+                                               u8 *__restrict__ bwt, u32 *__restrict__ meta,
+                                               u8 *__restrict__ symmap_out) {
     const u32 b = blockIdx.x;
     const int lane = lane_id();
     const int wv = wave_id();
@@ -287,6 +288,10 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
             }
         } while (0);
         if (lane == 0) { s_status = status; s_eob = (u32)eob; s_nsel = (u32)nsel; s_orig = orig; s_crc = crc; }
+        // the initial list (the block's bytes in order) for kd_imtf_compose
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        ((u32 *)(symmap_out + (size_t)b * 256))[lane] = ((const u32 *)symmap)[lane];
     }
     __syncthreads();
     const u32 status0 = s_status;
@@ -315,10 +320,18 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                 bp = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(cons & 31u));
                 br.load_window(wbase);
             }
+            // a step is "near the end" when fewer than 128 bits of the stream lie beyond bp: as a
+            // window-relative bound, recomputed with the window
+            auto near_bound = [&](u64 wb) -> u32 {
+                const u64 w0 = wb * 32u + 128u;
+                return nbits > w0 ? (u32)min(nbits - w0, (u64)0xfffffffeu) + 1u : 0u;
+            };
+            u32 nearbp = near_bound(wbase); // bp >= nearbp: near the end
             while (!stop) {
                 // wave-uniform state in scalar registers (see KdBits::pin)
                 wbase = KdBits::uni64(wbase);
                 bp = (u32)__builtin_amdgcn_readfirstlane((int)bp);
+                nearbp = (u32)__builtin_amdgcn_readfirstlane((int)nearbp);
                 gleft = __builtin_amdgcn_readfirstlane(gleft);
                 gidx = __builtin_amdgcn_readfirstlane(gidx);
                 cur = __builtin_amdgcn_readfirstlane(cur);
@@ -343,14 +356,14 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                         wbase += bp >> 5;
                         bp &= 31u;
                         br.load_window(wbase);
+                        nearbp = near_bound(wbase);
                     }
                     const u32 a = bp + (u32)lane;
                     const u32 d0 = __builtin_bswap32(win[a >> 5]), d1 = __builtin_bswap32(win[(a >> 5) + 1]);
                     const u32 fld = (u32)((((u64)d0 << 32) | (u64)d1) >> (32u - (a & 31u))); // 32 bits at offset a
                     const u32 myent = lut[cur][fld >> (32 - KD_LUT_BITS)];
-                    const u64 here = wbase * 32u + (u64)bp; // stream bit of the next symbol
                     // (no bit past the end can be used by this step while 128 more bits exist)
-                    const bool nearend = here + 128u > nbits;
+                    const bool nearend = bp >= nearbp;
                     u32 off = 0;
                     if (!nearend) {
                         // entries the scalar chain stops at: no entry, no symbol, end of block; the
@@ -361,13 +374,30 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                         const u32 ment = (myent & 0xffffu) | (nx << 16) | (nx > 63u ? 0x800000u : 0u) |
                                          ((myent == 0 || sy == 511u || (int)sy == eob) ? 0x8000u : 0u);
                         u32 n = 0, e;
-                        do {
-                            e = __builtin_amdgcn_readlane(ment, (int)off);
-                            if (e & 0x8000u) break;
-                            visited |= 1ull << off;
-                            off = (e >> 16) & 127u;
-                            n++;
-                        } while (!(e & 0x800000u) && n < (u32)gleft);
+                        const u32 glim = (u32)gleft;
+                        // The chain, 11 instructions per symbol (the compiler makes 16 of the same
+                        // loop, with the conditions turned into mask arithmetic):
+                        //   do { e = readlane(ment, off); if (e & 0x8000) break; visited |= 1 << off;
+                        //        off = (e >> 16) & 127; n++; } while (!(e & 0x800000) && n < glim);
+                        {
+                            u64 t64;
+                            asm volatile("1:\n\t"
+                                         "v_readlane_b32 %[e], %[ment], %[off]\n\t"
+                                         "s_bitcmp1_b32 %[e], 15\n\t"
+                                         "s_cbranch_scc1 2f\n\t"
+                                         "s_lshl_b64 %[t], 1, %[off]\n\t"
+                                         "s_or_b64 %[vis], %[vis], %[t]\n\t"
+                                         "s_bfe_u32 %[off], %[e], 0x70010\n\t"
+                                         "s_add_u32 %[n], %[n], 1\n\t"
+                                         "s_bitcmp1_b32 %[e], 23\n\t"
+                                         "s_cbranch_scc1 2f\n\t"
+                                         "s_cmp_lt_u32 %[n], %[glim]\n\t"
+                                         "s_cbranch_scc1 1b\n\t"
+                                         "2:"
+                                         : [e] "=&s"(e), [off] "+s"(off), [vis] "+s"(visited), [n] "+s"(n), [t] "=&s"(t64)
+                                         : [ment] "v"(ment), [glim] "s"(glim)
+                                         : "scc");
+                        }
                         if (n > 0) {
                             // the lanes whose offset the chain visited hold its symbols, in order
                             fast = true;
@@ -386,6 +416,7 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                         }
                     } else {
                         // the last bits of the stream: test every symbol for the end of the data
+                        const u64 here = wbase * 32u + (u64)bp; // stream bit of the next symbol
                         while (gleft > 0 && off <= 63u) {
                             const u32 e = __builtin_amdgcn_readlane(myent, (int)off);
                             if (e == 0) break; // longer than 10 bits (or a table the block does not define)
@@ -461,16 +492,15 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
         } else {
             // ---- consumer: symbols -> BWT bytes, S/BZip2BlockDecompressor.swift:266-321.  The MTF
             // list holds the bytes themselves (the symbol map applied to the identity list).
-            // A batch of up to 64 ring entries is handled in the vector domain (lane = entry) except
-            // for the one thing that is serial, the list: what every entry emits (a plain symbol 1
+            // A batch of up to 64 ring entries is handled in the vector domain (lane = entry): what
+            // every entry emits (a plain symbol 1
             // byte, the j-th symbol of a run stretch (1 + RUNB) << j copies of the current byte -- all
             // bytes of a stretch are equal, so each run symbol writes its own share), the output
             // offsets (a wave scan), the reference's size checks (they are monotone in those prefix
             // sums: the first lane that violates one is where the reference stops) and the stores.
-            // The serial loop only moves list entries: a lone wave issues one instruction every
-            // 6.5-10 cycles, so instructions per symbol are what counts.
-            u32 L = ((const u32 *)symmap)[lane];
-            u32 curbyte = symmap[0], len = 0;
+            // Nothing here is serial over the symbols: a lone wave issues one instruction every
+            // 6.5-10 cycles, so the serial list moves are left to kd_imtf_*.
+            u32 len = 0;
             u32 runk = 0, runrep = 0; // an open run stretch: symbols so far, length so far
             u32 tail = 0, status = KS_OK;
             bool done = false;
@@ -521,43 +551,11 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                 const u64 stopm = __ballot(st != KS_OK || iseob);
                 const u32 fstop = stopm ? (u32)__builtin_ctzll(stopm) : 64u; // entries before it are processed
                 const u64 live = fstop >= 64u ? ~0ull : ((1ull << fstop) - 1ull);
-                // ---- the list: plain symbols in order; vals = the byte of every plain entry
-                const u32 pq = (mine - 1u) & 255u;
-                const u32 pk = (pq >> 2) | ((pq & 3u) << 11); // lane | byte shift << 8
-                u32 vals = 0;
-                u64 pm = plainm & live;
-                u32 lastv = curbyte;
-                while (pm) {
-                    const int q = __builtin_ctzll(pm);
-                    asm("s_bitset0_b64 %0, %1" : "+s"(pm) : "s"(q));
-                    const u32 k2 = __builtin_amdgcn_readlane(pk, q);
-                    const int src = (int)(k2 & 255u);
-                    const u32 sh = k2 >> 8;
-                    const u32 m = 0xffffffffu >> (24u - sh); // bytes 0..k of the source lane's word move
-                    u32 v;
-                    if (src == 0) {
-                        // one of the first four entries: lane 0's word in scalar arithmetic
-                        u32 F = (u32)__builtin_amdgcn_readlane((int)L, 0);
-                        v = (F >> sh) & 255u;
-                        F = (((F << 8) | v) & m) | (F & ~m);
-                        L = write_lane(L, F, 0);
-                    } else {
-                        v = (__builtin_amdgcn_readlane(L, src) >> sh) & 255u;
-                        // every word takes the top byte of the word before it, the first one v
-                        // (wave_shr leaves lane 0 with the `old` operand)
-                        const u32 up = (u32)__builtin_amdgcn_update_dpp((int)(v << 24), (int)L, 0x138, 0xf, 0xf, false);
-                        const u32 shifted = __builtin_amdgcn_alignbit(L, up, 24); // (L << 8) | (up >> 24)
-                        const u32 at_src = (shifted & m) | (L & ~m);
-                        L = (lane < src) ? shifted : ((lane == src) ? at_src : L);
-                    }
-                    vals = write_lane(vals, v, q);
-                    lastv = v;
-                }
-                // ---- bytes out: a run symbol repeats the byte of the nearest plain entry before it
-                const u64 pb = plainm & live & lt;
-                const int psrc = pb ? 63 - __clzll((unsigned long long)pb) : 0;
-                const u32 prevv = (u32)__shfl((int)vals, psrc, 64);
-                const u32 byte = isplain ? vals : (pb ? prevv : curbyte);
+                // ---- what is written is the MTF position of every output byte: a plain symbol's
+                // own (>= 1), 0 for the bytes of a run (a run repeats the front of the list, and RUNA /
+                // RUNB stand for runs of position 0).  The list itself is undone afterwards, for all
+                // blocks and all their chunks in parallel (kd_imtf_*).
+                const u32 byte = isplain ? ((mine - 1u) & 255u) : 0u;
                 const bool act = (live >> lane) & 1ull;
                 const u32 o = len + E;
                 const u32 cnt = act ? min(e, o < block_size ? block_size - o : 0u) : 0u; // never past the slot
@@ -578,7 +576,6 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                 const u32 nproc = min(fstop, avail);
                 if (nproc > 0) {
                     len += __builtin_amdgcn_readlane(inc, (int)nproc - 1);
-                    curbyte = lastv;
                     if ((runm >> (nproc - 1)) & 1ull) {
                         runk = __builtin_amdgcn_readlane(expo, (int)nproc - 1) + 1u;
                         runrep = __builtin_amdgcn_readlane(R, (int)nproc - 1);
@@ -611,6 +608,137 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
         mt[KM_CRC] = s_crc;
         mt[KM_END_LO] = s_end_lo;
         mt[KM_END_HI] = s_end_hi;
+    }
+}
+
+// ------------------------------------------------------------------ inverse MTF, parallel
+// kd_huff leaves the MTF position of every output byte.  Undoing the list is serial along a
+// block, but what a stretch of positions does to the list does not depend on the list's contents:
+// it is a permutation of the 256 places.  So a block is cut into chunks of KD_MCHUNK positions and
+//   kd_imtf_perm    : every chunk applies its moves to the identity -> its permutation
+//   kd_imtf_compose : one wave per block walks the chunks: entry list of chunk c + 1 =
+//                     entry list of chunk c, permuted (a 256-byte gather), from the block's bytes
+//   kd_imtf_apply   : every chunk replays its moves on its entry list and writes the bytes
+// (the mirror image of the encoder's k3_mtf_recency / compose / replay).  The list is 4 entries
+// per lane, entry 0 = front, as bytes of a word.
+#define KD_MCHUNK 1024
+
+// The moves of one row of 64 positions (lane = position, 0 = none).  WANT: returns the lane's byte.
+template <bool WANT>
+__device__ __forceinline__ u32 kd_imtf_row(u32 &L, u32 p, bool valid) {
+    const int lane = lane_id();
+    const u32 front0 = (u32)__builtin_amdgcn_readlane((int)L, 0) & 255u; // a position 0 repeats the front
+    const u32 pk = (p >> 2) | ((p & 3u) << 11); // lane | byte shift << 8
+    const u64 nzm = __ballot(valid && p != 0);
+    u64 nz = nzm;
+    u32 vals = 0;
+    while (nz) {
+        const int q = __builtin_ctzll(nz);
+        asm("s_bitset0_b64 %0, %1" : "+s"(nz) : "s"(q));
+        const u32 k2 = __builtin_amdgcn_readlane(pk, q);
+        const int src = (int)(k2 & 255u);
+        const u32 sh = k2 >> 8;
+        const u32 m = 0xffffffffu >> (24u - sh); // bytes 0..k of the source lane's word move
+        u32 v;
+        if (src == 0) {
+            // one of the first four entries: lane 0's word in scalar arithmetic
+            u32 F = (u32)__builtin_amdgcn_readlane((int)L, 0);
+            v = (F >> sh) & 255u;
+            F = (((F << 8) | v) & m) | (F & ~m);
+            L = write_lane(L, F, 0);
+        } else {
+            v = (__builtin_amdgcn_readlane(L, src) >> sh) & 255u;
+            // every word takes the top byte of the word before it, the first one v (wave_shr leaves
+            // lane 0 with the `old` operand)
+            const u32 up = (u32)__builtin_amdgcn_update_dpp((int)(v << 24), (int)L, 0x138, 0xf, 0xf, false);
+            const u32 shifted = __builtin_amdgcn_alignbit(L, up, 24); // (L << 8) | (up >> 24)
+            const u32 at_src = (shifted & m) | (L & ~m);
+            L = (lane < src) ? shifted : ((lane == src) ? at_src : L);
+        }
+        if (WANT) vals = write_lane(vals, v, q);
+    }
+    if (!WANT) return 0;
+    // the byte of a position 0 is that of the nearest move at or before it (or the row's first front)
+    const u64 upto = nzm & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+    const int s = upto ? 63 - __clzll((unsigned long long)upto) : 0;
+    const u32 pv = (u32)__shfl((int)vals, s, 64);
+    return upto ? pv : front0;
+}
+
+__global__ __launch_bounds__(256) void kd_imtf_perm(const u8 *__restrict__ bwt, const u32 *__restrict__ slot,
+                                                    const u32 *__restrict__ nArr, u32 S, u32 CH,
+                                                    u8 *__restrict__ perm) {
+    const u32 k = blockIdx.y, n = nArr[k];
+    const int lane = lane_id();
+    const u32 c = blockIdx.x * 4u + (u32)wave_id();
+    const u32 base = c * KD_MCHUNK;
+    if (base >= n) return;
+    const u8 *pos = bwt + (size_t)slot[k] * S;
+    u8 rowv[KD_MCHUNK / 64];
+#pragma unroll
+    for (int r = 0; r < KD_MCHUNK / 64; r++) rowv[r] = pos[min(base + r * 64 + lane, n - 1)];
+    const u32 l4 = (u32)lane * 4u;
+    u32 L = l4 | ((l4 + 1u) << 8) | ((l4 + 2u) << 16) | ((l4 + 3u) << 24);
+#pragma unroll
+    for (int r = 0; r < KD_MCHUNK / 64; r++) {
+        const u32 j = base + r * 64 + lane;
+        if (base + r * 64 >= n) break;
+        (void)kd_imtf_row<false>(L, rowv[r], j < n);
+    }
+    ((u32 *)(perm + ((size_t)k * CH + c) * 256))[lane] = L;
+}
+
+// one wave per block: perm[c] := entry list of chunk c
+__global__ __launch_bounds__(64) void kd_imtf_compose(const u32 *__restrict__ slot, const u32 *__restrict__ nArr,
+                                                      const u8 *__restrict__ symmap, u32 CH,
+                                                      u8 *__restrict__ perm) {
+    const u32 k = blockIdx.x, n = nArr[k];
+    const int lane = lane_id();
+    const u32 chunks = (n + KD_MCHUNK - 1) / KD_MCHUNK;
+    __shared__ __attribute__((aligned(16))) u8 cur[256];
+    ((u32 *)cur)[lane] = ((const u32 *)(symmap + (size_t)slot[k] * 256))[lane];
+    __syncthreads();
+    u32 *pw = (u32 *)(perm + (size_t)k * CH * 256);
+    // the permutations do not depend on the walk: fetch them 8 chunks at a time
+    constexpr int PF = 8;
+    for (u32 c0 = 0; c0 < chunks; c0 += PF) {
+        u32 pv[PF];
+#pragma unroll
+        for (int q = 0; q < PF; q++) pv[q] = (c0 + q < chunks) ? pw[(size_t)(c0 + q) * 64 + lane] : 0u;
+#pragma unroll
+        for (int q = 0; q < PF; q++) {
+            if (c0 + q >= chunks) break;
+            const u32 w = pv[q];
+            const u32 now = ((u32 *)cur)[lane];
+            pw[(size_t)(c0 + q) * 64 + lane] = now; // the chunk's entry list
+            const u32 nv = (u32)cur[w & 255u] | ((u32)cur[(w >> 8) & 255u] << 8) |
+                           ((u32)cur[(w >> 16) & 255u] << 16) | ((u32)cur[w >> 24] << 24);
+            __syncthreads();
+            ((u32 *)cur)[lane] = nv;
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void kd_imtf_apply(u8 *__restrict__ bwt, const u32 *__restrict__ slot,
+                                                     const u32 *__restrict__ nArr, u32 S, u32 CH,
+                                                     const u8 *__restrict__ perm) {
+    const u32 k = blockIdx.y, n = nArr[k];
+    const int lane = lane_id();
+    const u32 c = blockIdx.x * 4u + (u32)wave_id();
+    const u32 base = c * KD_MCHUNK;
+    if (base >= n) return;
+    u8 *pos = bwt + (size_t)slot[k] * S;
+    u8 rowv[KD_MCHUNK / 64];
+#pragma unroll
+    for (int r = 0; r < KD_MCHUNK / 64; r++) rowv[r] = pos[min(base + r * 64 + lane, n - 1)];
+    u32 L = ((const u32 *)(perm + ((size_t)k * CH + c) * 256))[lane];
+#pragma unroll
+    for (int r = 0; r < KD_MCHUNK / 64; r++) {
+        const u32 j = base + r * 64 + lane;
+        if (base + r * 64 >= n) break;
+        const u32 v = kd_imtf_row<true>(L, rowv[r], j < n);
+        if (j < n) pos[j] = (u8)v;
     }
 }
 
@@ -1003,7 +1131,8 @@ int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size
     const u32 ETPB_MAX = (u32)(((u64)block_size * 52 + 4095) / 4096 + 2);
     u64 *d_cand = nullptr;
     u32 *d_ncand = nullptr;
-    u8 *d_bwt = nullptr, *d_tt = nullptr;
+    u8 *d_bwt = nullptr, *d_tt = nullptr, *d_symmap = nullptr, *d_perm = nullptr;
+    const u32 CH = S / KD_MCHUNK + 1; // chunks of the inverse MTF per block slot
     u32 *d_meta = nullptr, *d_slot = nullptr, *d_n = nullptr, *d_orig = nullptr, *d_base = nullptr, *d_merged = nullptr;
     uint2 *d_rinfo = nullptr, *d_visits = nullptr;
     u32 *d_nvis = nullptr, *d_cyc = nullptr, *d_outlen = nullptr, *d_flags = nullptr, *d_outbase = nullptr, *d_crc = nullptr;
@@ -1015,6 +1144,8 @@ int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size
         d_bwt = A.get<u8>((size_t)NB * S);
         d_tt = A.get<u8>((size_t)NB * S);
         d_meta = A.get<u32>((size_t)NB * KM_WORDS);
+        d_symmap = A.get<u8>((size_t)NB * 256);
+        d_perm = A.get<u8>((size_t)NB * CH * 256);
         d_slot = A.get<u32>(NB); d_n = A.get<u32>(NB); d_orig = A.get<u32>(NB);
         d_base = A.get<u32>((size_t)NB * KD_MPARTS * 256);
         d_merged = A.get<u32>((size_t)NB * S);
@@ -1067,7 +1198,7 @@ int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size
         if (it == cand.end() || *it != cur) break; // not a block: end marker or garbage, below
         const u32 i0 = (u32)(it - cand.begin());
         const u32 nbatch = std::min<u32>(ncand - i0, NB);
-        kd_huff<<<nbatch, 128, 0, st>>>(d_in, nbytes, d_cand + i0, block_size, S, d_bwt, d_meta);
+        kd_huff<<<nbatch, 128, 0, st>>>(d_in, nbytes, d_cand + i0, block_size, S, d_bwt, d_meta, d_symmap);
         KCHECK();
         HIPCHK(hipMemcpyAsync(meta.data(), d_meta, (size_t)nbatch * KM_WORDS * sizeof(u32),
                               hipMemcpyDeviceToHost, st));
@@ -1105,6 +1236,14 @@ int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size
             HIPCHK(hipMemcpyAsync(d_n, h_n.data(), nb * 4, hipMemcpyHostToDevice, st));
             HIPCHK(hipMemcpyAsync(d_orig, h_orig.data(), nb * 4, hipMemcpyHostToDevice, st));
             if (maxn) {
+                // MTF positions -> BWT bytes, in place
+                const dim3 gm((maxn + 4 * KD_MCHUNK - 1) / (4 * KD_MCHUNK), nb);
+                kd_imtf_perm<<<gm, 256, 0, st>>>(d_bwt, d_slot, d_n, S, CH, d_perm);
+                KCHECK();
+                kd_imtf_compose<<<nb, 64, 0, st>>>(d_slot, d_n, d_symmap, CH, d_perm);
+                KCHECK();
+                kd_imtf_apply<<<gm, 256, 0, st>>>(d_bwt, d_slot, d_n, S, CH, d_perm);
+                KCHECK();
                 kd_hist<<<nb, 256, 0, st>>>(d_bwt, d_slot, d_n, S, d_base);
                 KCHECK();
                 kd_merge<<<dim3(KD_MPARTS, nb), 64, 0, st>>>(d_bwt, d_slot, d_n, S, d_base, d_merged);
