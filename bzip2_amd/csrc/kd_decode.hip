@@ -133,6 +133,34 @@ struct KdBits {
 // stores: a memory round trip per batch of 64 symbols).
 #define KD_LDS_ORDER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
+// The chain through one register of window entries (lane = bit offset), 11 instructions per symbol
+// (the compiler makes 16 of the same loop, with the conditions turned into mask arithmetic):
+//   do { e = readlane(ment, off); if (e & 0x8000) break; visited |= 1 << off;
+//        off = (e >> 16) & 127; n++; } while (!(e & 0x800000) && n < lim);
+// Entry: bit 15 = stop before it (no entry / no symbol / end of block), bits 16..22 = offset of the
+// next code, bit 23 = that offset lies outside the register.  Returns the last entry read.
+__device__ __forceinline__ u32 kd_chain(u32 ment, u32 &off, u32 &n, u32 lim, u64 &visited) {
+    u32 e;
+    u64 t64;
+    asm volatile("1:\n\t"
+                 "v_readlane_b32 %[e], %[ment], %[off]\n\t"
+                 "s_bitcmp1_b32 %[e], 15\n\t"
+                 "s_cbranch_scc1 2f\n\t"
+                 "s_lshl_b64 %[t], 1, %[off]\n\t"
+                 "s_or_b64 %[vis], %[vis], %[t]\n\t"
+                 "s_bfe_u32 %[off], %[e], 0x70010\n\t"
+                 "s_add_u32 %[n], %[n], 1\n\t"
+                 "s_bitcmp1_b32 %[e], 23\n\t"
+                 "s_cbranch_scc1 2f\n\t"
+                 "s_cmp_lt_u32 %[n], %[lim]\n\t"
+                 "s_cbranch_scc1 1b\n\t"
+                 "2:"
+                 : [e] "=&s"(e), [off] "+s"(off), [vis] "+s"(visited), [n] "+s"(n), [t] "=&s"(t64)
+                 : [ment] "v"(ment), [lim] "s"(lim)
+                 : "scc");
+    return e;
+}
+
 // Two waves per block.  Wave 0 parses the header and builds the tables, then only decodes Huffman
 // symbols into an LDS ring; wave 1 turns symbols into BWT bytes (runs, inverse MTF).  The two serial
 // chains run on different SIMDs of the CU.  Errors travel through the ring in symbol order, so the
@@ -320,10 +348,10 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                 bp = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(cons & 31u));
                 br.load_window(wbase);
             }
-            // a step is "near the end" when fewer than 128 bits of the stream lie beyond bp: as a
+            // a step is "near the end" when fewer than 256 bits of the stream lie beyond bp: as a
             // window-relative bound, recomputed with the window
             auto near_bound = [&](u64 wb) -> u32 {
-                const u64 w0 = wb * 32u + 128u;
+                const u64 w0 = wb * 32u + 256u;
                 return nbits > w0 ? (u32)min(nbits - w0, (u64)0xfffffffeu) + 1u : 0u;
             };
             u32 nearbp = near_bound(wbase); // bp >= nearbp: near the end
@@ -338,8 +366,8 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                 head = (u32)__builtin_amdgcn_readfirstlane((int)head);
                 tail_seen = (u32)__builtin_amdgcn_readfirstlane((int)tail_seen);
                 published = (u32)__builtin_amdgcn_readfirstlane((int)published);
-                u32 mysym = 0, cnt = 0;
-                u64 visited = 0;
+                u32 mysym = 0, mysym1 = 0, cnt = 0;
+                u64 visited = 0, visited1 = 0;
                 bool fast = false;
                 if (gleft == 0) {
                     gleft = GROUP;
@@ -351,8 +379,8 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                     }
                 }
                 if (!stop) {
-                    // the lanes read the bits [bp, bp + 63 + 32) and one word more
-                    if (bp + 160u > KD_WIN * 8u) {
+                    // the lanes read the bits [bp, bp + 127 + 32) and one word more
+                    if (bp + 256u > KD_WIN * 8u) {
                         wbase += bp >> 5;
                         bp &= 31u;
                         br.load_window(wbase);
@@ -362,48 +390,41 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                     const u32 d0 = __builtin_bswap32(win[a >> 5]), d1 = __builtin_bswap32(win[(a >> 5) + 1]);
                     const u32 fld = (u32)((((u64)d0 << 32) | (u64)d1) >> (32u - (a & 31u))); // 32 bits at offset a
                     const u32 myent = lut[cur][fld >> (32 - KD_LUT_BITS)];
-                    // (no bit past the end can be used by this step while 128 more bits exist)
+                    // (no bit past the end can be used by this step while 256 more bits exist)
                     const bool nearend = bp >= nearbp;
                     u32 off = 0;
                     if (!nearend) {
-                        // entries the scalar chain stops at: no entry, no symbol, end of block; the
-                        // chain follows the next offset stored in the entry (bits 16..22) and ends after
-                        // the entry whose successor lies outside the 64 offsets (bit 23)
-                        const u32 sy = myent >> 5;
-                        const u32 nx = (u32)lane + (myent & 31u);
+                        // Two registers of entries per step, for the 128 bit offsets from bp on (the
+                        // step's fixed cost is as much as the chain through ~8 symbols).
+                        // Entries the scalar chain stops at: no entry, no symbol, end of block; the
+                        // chain follows the next offset stored in the entry (bits 16..22) and leaves a
+                        // register after the entry whose successor lies outside its 64 offsets (bit 23)
+                        const u32 d2 = __builtin_bswap32(win[(a >> 5) + 2]), d3 = __builtin_bswap32(win[(a >> 5) + 3]);
+                        const u32 fld1 = (u32)((((u64)d2 << 32) | (u64)d3) >> (32u - (a & 31u))); // offset a + 64
+                        const u32 myent1 = lut[cur][fld1 >> (32 - KD_LUT_BITS)];
+                        const u32 sy = myent >> 5, sy1 = myent1 >> 5;
+                        const u32 nx = (u32)lane + (myent & 31u), nx1 = (u32)lane + (myent1 & 31u);
                         const u32 ment = (myent & 0xffffu) | (nx << 16) | (nx > 63u ? 0x800000u : 0u) |
                                          ((myent == 0 || sy == 511u || (int)sy == eob) ? 0x8000u : 0u);
-                        u32 n = 0, e;
+                        const u32 ment1 = (myent1 & 0xffffu) | (nx1 << 16) | (nx1 > 63u ? 0x800000u : 0u) |
+                                          ((myent1 == 0 || sy1 == 511u || (int)sy1 == eob) ? 0x8000u : 0u);
+                        u32 n = 0;
                         const u32 glim = (u32)gleft;
-                        // The chain, 11 instructions per symbol (the compiler makes 16 of the same
-                        // loop, with the conditions turned into mask arithmetic):
-                        //   do { e = readlane(ment, off); if (e & 0x8000) break; visited |= 1 << off;
-                        //        off = (e >> 16) & 127; n++; } while (!(e & 0x800000) && n < glim);
-                        {
-                            u64 t64;
-                            asm volatile("1:\n\t"
-                                         "v_readlane_b32 %[e], %[ment], %[off]\n\t"
-                                         "s_bitcmp1_b32 %[e], 15\n\t"
-                                         "s_cbranch_scc1 2f\n\t"
-                                         "s_lshl_b64 %[t], 1, %[off]\n\t"
-                                         "s_or_b64 %[vis], %[vis], %[t]\n\t"
-                                         "s_bfe_u32 %[off], %[e], 0x70010\n\t"
-                                         "s_add_u32 %[n], %[n], 1\n\t"
-                                         "s_bitcmp1_b32 %[e], 23\n\t"
-                                         "s_cbranch_scc1 2f\n\t"
-                                         "s_cmp_lt_u32 %[n], %[glim]\n\t"
-                                         "s_cbranch_scc1 1b\n\t"
-                                         "2:"
-                                         : [e] "=&s"(e), [off] "+s"(off), [vis] "+s"(visited), [n] "+s"(n), [t] "=&s"(t64)
-                                         : [ment] "v"(ment), [glim] "s"(glim)
-                                         : "scc");
-                        }
+                        const u32 e = kd_chain(ment, off, n, glim, visited);
                         if (n > 0) {
                             // the lanes whose offset the chain visited hold its symbols, in order
                             fast = true;
+                            mysym = sy;
+                            if (!(e & 0x8000u) && (e & 0x800000u) && n < glim) {
+                                // on into the second register: offsets 64 ..
+                                u32 off1 = off - 64u, n1 = 0;
+                                (void)kd_chain(ment1, off1, n1, glim - n, visited1);
+                                off = 64u + off1;
+                                n += n1;
+                                mysym1 = sy1;
+                            }
                             gleft -= (int)n;
                             cnt = n;
-                            mysym = sy;
                         } else {
                             const u32 e0 = __builtin_amdgcn_readlane(myent, 0);
                             if (e0 != 0) { // no symbol for this code, or the end of the block
@@ -472,8 +493,11 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
                     if (stop == 2) break;
                 }
                 if (fast) {
+                    const u64 ltm = (1ull << lane) - 1ull;
                     if ((visited >> lane) & 1ull)
-                        ring[(head + (u32)__popcll(visited & ((1ull << lane) - 1ull))) % KD_RING] = (u16)mysym;
+                        ring[(head + (u32)__popcll(visited & ltm)) % KD_RING] = (u16)mysym;
+                    if ((visited1 >> lane) & 1ull)
+                        ring[(head + (u32)__popcll(visited) + (u32)__popcll(visited1 & ltm)) % KD_RING] = (u16)mysym1;
                 } else if ((u32)lane < cnt) {
                     ring[(head + lane) % KD_RING] = (u16)mysym;
                 }
