@@ -6,9 +6,13 @@
 // HBM.  The reference decodes one block after the other; here every block is decoded at once:
 //   kd_scan_magic : every bit offset is tested for the 48-bit block magic (blocks abut at any bit)
 //   kd_huff       : two wavefronts per candidate: header, selectors, code lengths, canonical tables,
-//                   then wave 0 decodes Huffman symbols into an LDS ring and wave 1 turns them into
-//                   BWT bytes (RUNA-RUNB runs, inverse MTF: list 4 entries per lane, DPP rotate);
+//                   then wave 0 decodes Huffman symbols into an LDS ring (every lane looks up the code
+//                   at its own bit offset of a 128-bit window, a scalar chain follows the real codes)
+//                   and wave 1 turns batches of 64 symbols into MTF positions, one per output byte
+//                   (RUNA-RUNB runs become runs of position 0), with the reference's size checks;
 //                   also origin pointer, stored CRC, end bit
+//   kd_imtf_*     : MTF positions -> BWT bytes for all chunks of all blocks at once (a chunk's effect
+//                   on the list is a permutation; permutations are composed per block)
 //   host          : walks the chain magic -> end bit -> magic from bit 32; anything a candidate
 //                   that is not on the chain decoded is ignored
 //   kd_hist / kd_merge : stable counting sort of the BWT bytes = the reference's merged pointers
@@ -162,9 +166,10 @@ __device__ __forceinline__ u32 kd_chain(u32 ment, u32 &off, u32 &n, u32 lim, u64
 }
 
 // Two waves per block.  Wave 0 parses the header and builds the tables, then only decodes Huffman
-// symbols into an LDS ring; wave 1 turns symbols into BWT bytes (runs, inverse MTF).  The two serial
-// chains run on different SIMDs of the CU.  Errors travel through the ring in symbol order, so the
-// first one in the reference's order wins; a wave that gives up raises s_abort for the other.
+// symbols into an LDS ring; wave 1 turns symbols into the MTF position of every output byte (runs
+// expanded) and applies the reference's size checks.  The two run on different SIMDs of the CU.
+// Errors travel through the ring in symbol order, so the first one in the reference's order wins; a
+// wave that gives up raises s_abort for the other.
 __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nbytes,
                                                const u64 *__restrict__ cand, u32 block_size, u32 S,
                                                u8 *__restrict__ bwt, u32 *__restrict__ meta,
