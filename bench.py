@@ -117,8 +117,10 @@ def main():
         # one stream of world x seg MiB; rank r holds [lo, end) = its nominal range + lookahead
         n_total = world * seg * corpus.MIB
         lo, hi = parallel.nominal_ranges(n_total, world)[rank]
-        look_segs = 2  # a block that starts in this rank's last segment ends within the next two
-        s0, s1 = lo // corpus.MIB, min(world * seg, hi // corpus.MIB + look_segs)
+        # a block that starts in this rank's last segment ends within the next two; six more are
+        # resident (not scanned) in case the chain asks for more lookahead (plan_rank grows it x4)
+        look_segs, held_segs = 2, 8
+        s0, s1 = lo // corpus.MIB, min(world * seg, hi // corpus.MIB + held_segs)
         parts = [corpus.segment(corpus._KINDS[i % 8], corpus.MIB, corpus.STREAM1G_SEED + i) for i in range(s0, s1)]
         mine = np.concatenate(parts)
         end = s1 * corpus.MIB
@@ -142,7 +144,7 @@ def main():
         # gloo groups for the host-side messages, one per thread that uses it
         hop_group = dist.new_group(backend="gloo")   # the block chain: one int64 per hop (plan thread)
         meta_group = dist.new_group(backend="gloo")  # segment sizes and block CRCs (this thread)
-        cap_seg = L.bz2hip_compress_bound(n_in + look_segs * corpus.MIB)
+        cap_seg = L.bz2hip_compress_bound(n_in + held_segs * corpus.MIB)
         seg_words = (cap_seg + 3) // 4 * 4
         d_none = torch.zeros(8, dtype=torch.uint8, device=dev)
         # rank 0: receive buffers for every other rank's segment, the stream, and a context of its
@@ -165,7 +167,7 @@ def main():
 
         def plan(eng):
             return parallel.plan_rank(eng, level, rank, world, n_total, recv_first, send_next,
-                                      lookahead=end - hi if rank + 1 < world else 0)
+                                      lookahead=min(end - hi, look_segs * corpus.MIB) if rank + 1 < world else 0)
 
         def wait_current_stream():
             # the transfers are ordered on torch's current stream; wait for that stream only (a
