@@ -237,6 +237,30 @@ def main():
             for _ in range(k):
                 out = step()
             return out
+    else:
+        # connections are made on first use (RCCL point-to-point pairs, gloo pairs): open every one
+        # this run uses with a 8-byte message, so that --warmup 0 does not time connection set-up
+        z = torch.zeros(1, dtype=torch.int64)
+        dist.gather(z, [torch.zeros_like(z) for _ in range(world)] if rank == 0 else None, dst=0, group=meta_group)
+        if rank > 0:
+            dist.recv(z, src=rank - 1, group=hop_group)
+        if rank + 1 < world:
+            dist.send(z, dst=rank + 1, group=hop_group)
+        if cpu_comm:
+            if rank == 0:
+                for r in range(1, world):
+                    dist.recv(z, src=r, group=meta_group)
+            else:
+                dist.send(z, dst=0, group=meta_group)
+        else:
+            dz = torch.zeros(8, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                ops = [dist.P2POp(dist.irecv, d_recv[r][:8], r) for r in range(1, world)]
+            else:
+                ops = [dist.P2POp(dist.isend, dz, 0)]
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            torch.cuda.synchronize()
     out_len = run_streams(args.warmup)
     ctx.profile_reset()
     barrier()
