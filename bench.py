@@ -101,6 +101,7 @@ def main():
     seg = args.segments
     level = args.level
 
+    cpu_comm = False
     if world == 1:
         data = corpus.mixed(seg, corpus.MIXED256_SEED)
         workload = f"mixed{seg} ({seg} x 1 MiB segments, 8 kinds cycling), one stream on one GPU"
@@ -228,8 +229,13 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            if cpu_comm:
+                dist.barrier(group=meta_group)
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
+
+    transport = None
 
     if world == 1:
         def run_streams(k):
@@ -253,14 +259,25 @@ def main():
             else:
                 dist.send(z, dst=0, group=meta_group)
         else:
-            dz = torch.zeros(8, dtype=torch.uint8, device=dev)
-            if rank == 0:
-                ops = [dist.P2POp(dist.irecv, d_recv[r][:8], r) for r in range(1, world)]
-            else:
-                ops = [dist.P2POp(dist.isend, dz, 0)]
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-            torch.cuda.synchronize()
+            ok = 1
+            try:
+                dz = torch.zeros(8, dtype=torch.uint8, device=dev)
+                if rank == 0:
+                    ops = [dist.P2POp(dist.irecv, d_recv[r][:8], r) for r in range(1, world)]
+                else:
+                    ops = [dist.P2POp(dist.isend, dz, 0)]
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+                torch.cuda.synchronize()
+            except Exception as ex:  # the run still measures the path; the segments then travel through the host
+                ok = 0
+                print(f"[bench] rank {rank}: RCCL point-to-point set-up failed ({ex!r}); "
+                      f"segments will be gathered through host memory (gloo)", file=sys.stderr)
+            flag = torch.tensor([ok], dtype=torch.int64)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=meta_group)
+            if int(flag.item()) == 0:
+                cpu_comm = True
+        transport = ("host memory (gloo)" if cpu_comm else "RCCL point-to-point, GPU to GPU")
     out_len = run_streams(args.warmup)
     ctx.profile_reset()
     barrier()
@@ -271,8 +288,12 @@ def main():
     if world > 1:
         pipe.close()
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if cpu_comm:
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=meta_group)
+        else:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     stats = ctx.last_stats()
@@ -326,7 +347,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "level": level, "input_bytes_per_gpu": n_in,
                        "stream_bytes": n_total, "blocks_rank0": stats["blocks"],
-                       "compressed_bytes": out_len, "parallelism": f"blocks-sharded x{world}", **check},
+                       "compressed_bytes": out_len, "parallelism": f"blocks-sharded x{world}",
+                       **({"segment_transport": transport} if transport else {}), **check},
         }
         if prof:
             # dominant kernel class = the one with the most GPU time among those with a defined
@@ -432,7 +454,7 @@ def main():
         os.write(json_fd, (json.dumps(res) + "\n").encode())
     ctx.close()
     if world > 1:
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()
 
 

@@ -351,6 +351,47 @@ def test_stream1g_config4(ctx, orc):
     assert torch.equal(d_back[:dn], d_in)
 
 
+def test_stream2g_eight_ranks_bench_shape(ctx):
+    """What `bench.py --gpus 8` asks of the library, one "rank" after the other on this GPU: the 2 GiB
+    stream of the `stream1g` generator (more than 2^32 bits of output) in the bench's own slices
+    (nominal range + 8 MiB resident, 2 MiB lookahead), concatenated in HBM: byte-identical to the
+    stream compressed whole, and the GPU decoder returns the input."""
+    import hashlib
+    import torch
+    from bzip2_amd import parallel
+    world, seg, level = 8, 256, 9
+    n_total = world * seg * corpus.MIB
+    d = corpus.mixed(world * seg, corpus.STREAM1G_SEED)
+    d_whole = torch.from_numpy(d).to("cuda")
+    cap = ctx.L.bz2hip_compress_bound(n_total)
+    d_one = torch.empty(cap + 64, dtype=torch.uint8, device="cuda")
+    n1 = ctx.compress_device(d_whole.data_ptr(), n_total, level, d_one.data_ptr(), cap)
+    h1 = hashlib.sha256(d_one[:n1].cpu().numpy().tobytes()).hexdigest()
+    del d_one
+    hop, segs, keep = {}, [], []
+    for r in range(world):
+        lo, hi = parallel.nominal_ranges(n_total, world)[r]
+        end = min(world * seg, hi // corpus.MIB + 8) * corpus.MIB
+        eng = parallel.GpuShardEngine(ctx, 0)
+        eng.bind_device(d_whole[lo:end], lo, end)
+        nb = parallel.plan_rank(eng, level, r, world, n_total, lambda r=r: hop[r],
+                                lambda v, r=r: hop.__setitem__(r + 1, v),
+                                lookahead=min(end - hi, 2 * corpus.MIB) if r + 1 < world else 0)
+        assert nb > 200, (r, nb)
+        t, nbits, crcs = eng.compress_device()
+        t = t[: (nbits + 31) // 32 * 4 + 8].clone()
+        keep.append(t)
+        segs.append((t.data_ptr(), nbits, crcs))
+    assert sum(s[1] for s in segs) > 1 << 32
+    d_out = torch.empty(cap + 64, dtype=torch.uint8, device="cuda")
+    n8 = ctx.stitch_device(level, segs, d_out.data_ptr(), cap)
+    assert n8 == n1 and hashlib.sha256(d_out[:n8].cpu().numpy().tobytes()).hexdigest() == h1
+    d_back = torch.empty(n_total + 64, dtype=torch.uint8, device="cuda")
+    rc, dn = ctx.decompress_device(d_out.data_ptr(), n8, d_back.data_ptr(), n_total)
+    assert rc == 0 and dn == n_total
+    assert torch.equal(d_back[:dn], d_whole)
+
+
 def _repeat_family(seed):
     """Inputs built to exercise the long-repeat rules of the sorter (k2_bwt.hip: arithmetic
     progression rule, run rule): periodic regions of many periods and lengths, with mutations,
