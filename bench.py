@@ -414,19 +414,42 @@ def main():
             # SURVEY §8(d)'s definition: first byte submitted to last output byte in host memory,
             # through bz2hip_compress (PCIe both ways inside the clock).  Never `value`.
             h2h = {}
+            ctx_h = Context(device=local_rank, max_batch_blocks=args.batch, profile=0)  # no event pairs around kernels
             out_host = np.empty(cap, dtype=np.uint8)
             pin_in, pin_out = PinnedBuffer(n_in), PinnedBuffer(cap)
             pin_in.a[:] = data
             for name, src, dst in (("pageable", data, out_host), ("pinned", pin_in.a, pin_out.a)):
-                ctx.compress_into(src, level, dst)
+                ctx_h.compress_into(src, level, dst)
                 th = time.perf_counter()
                 for _ in range(max(args.steps, 1)):
-                    got = ctx.compress_into(src, level, dst)
+                    got = ctx_h.compress_into(src, level, dst)
                 th = (time.perf_counter() - th) / max(args.steps, 1)
                 h2h[name] = {"value": round(n_in / th / 1e6, 1), "unit": "MB/s", "ms_per_step": round(th * 1e3, 2),
                              "same_bytes": bool(got == out_len and dst[:got].tobytes() == comp)}
             h2h["ratio_pinned_to_device_resident"] = round(h2h["pinned"]["value"] / value, 3)
+            # the incremental API (BZip2OutputStream.write into a sink): 1 MiB writes, output read
+            # after every write; the context's worker thread compresses while the caller writes
+            def stream_pass():
+                got = []
+                ctx_h.stream_begin(level)
+                for o in range(0, n_in, 1 << 20):
+                    ctx_h.stream_write(data[o:o + (1 << 20)])
+                    while ctx_h.stream_pending():
+                        got.append(ctx_h.stream_read(1 << 24))
+                ctx_h.stream_finish()
+                while ctx_h.stream_pending():
+                    got.append(ctx_h.stream_read(1 << 24))
+                return got
+            for _ in range(3):  # the stream's buffers (page-locked chunks, output queue) reach their size
+                stream_pass()
+            th = time.perf_counter()
+            for _ in range(max(args.steps, 1)):
+                got = stream_pass()
+            th = (time.perf_counter() - th) / max(args.steps, 1)
+            h2h["stream_api_1MiB_writes"] = {"value": round(n_in / th / 1e6, 1), "unit": "MB/s",
+                                             "ms_per_step": round(th * 1e3, 2), "same_bytes": b"".join(got) == comp}
             res["host_to_host"] = h2h
+            ctx_h.close()
             pin_in.free()
             pin_out.free()
         if not args.no_cpu and world == 1:  # the CPU baseline is timed at N = 1 only

@@ -345,7 +345,8 @@ class Context:
         self._chk(self.L.bz2hip_stream_begin(self.h, level))
 
     def stream_write(self, data):
-        a = np.frombuffer(bytes(data), dtype=np.uint8)
+        a = np.ascontiguousarray(data, dtype=np.uint8) if isinstance(data, np.ndarray) else \
+            np.frombuffer(data, dtype=np.uint8)
         self._chk(self.L.bz2hip_stream_write(self.h, _p(a), a.size))
 
     def stream_finish(self):

@@ -206,9 +206,16 @@ static void ensure_staging(bz2hip_ctx *c, size_t in_bytes, size_t out_bytes) {
 }
 
 // ------------------------------------------------------------------ error plumbing
+static void stream_drain(bz2hip_ctx *c) {
+    if (!c || !c->sw.running) return;
+    std::unique_lock<std::mutex> lk(c->sw.mu);
+    c->sw.cv.wait(lk, [&] { return c->sw.active == 0; });
+}
+
 template <typename F>
 static int guarded(bz2hip_ctx *c, F f) {
     if (!c) return BZ2HIP_E_PARAM;
+    stream_drain(c); // the device side of the context is the stream worker's while it has work
     try {
         HIPCHK(hipSetDevice(c->device));
         return f();
@@ -292,6 +299,8 @@ extern "C" int bz2hip_create(bz2hip_ctx **out, const bz2hip_opts *opts) {
     c->radix_bits = env_int("BZ2HIP_RADIX_BITS", 8) == 10 ? 10u : 8u;
     c->radix_stage = env_int("BZ2HIP_RADIX_STAGE", 1) != 0;
     c->stream_chunk = (size_t)std::max(1, env_int("BZ2HIP_STREAM_CHUNK_MIB", (int)(STREAM_CHUNK >> 20))) << 20;
+    c->stream_sync = env_int("BZ2HIP_STREAM_SYNC", 0) != 0;
+    c->stream_least = (size_t)std::max(0, env_int("BZ2HIP_STREAM_LEAST_MIB", 0)) << 20;
     if (int m = env_int("BZ2HIP_DEC_PASS_MIB", 0)) c->dec_pass_bytes = (u64)std::max(1, m) << 20;
     try {
         k1_init_tables(c);
@@ -338,9 +347,23 @@ extern "C" int bz2hip_create(bz2hip_ctx **out, const bz2hip_opts *opts) {
 
 extern "C" void bz2hip_destroy(bz2hip_ctx *c) {
     if (!c) return;
+    if (c->sw.running) {
+        {
+            std::unique_lock<std::mutex> lk(c->sw.mu);
+            c->sw.cv.wait(lk, [&] { return c->sw.active == 0; });
+            c->sw.quit = true;
+        }
+        c->sw.cv.notify_all();
+        c->sw.th.join();
+        c->sw.running = false;
+    }
     for (bz2hip_ctx *p : c->peers) bz2hip_destroy(p);
     c->peers.clear();
     (void)hipSetDevice(c->device);
+    for (int k = 0; k < 2; k++)
+        if (c->sw.pin[k]) (void)hipHostFree(c->sw.pin[k]);
+    if (c->sw.d_in) (void)hipFree(c->sw.d_in);
+    if (c->sw.pin_out) (void)hipHostFree(c->sw.pin_out);
     if (c->d_shift) (void)hipFree(c->d_shift);
     if (c->dec_region) (void)hipFree(c->dec_region);
     (void)hipStreamSynchronize(c->stream);
@@ -1186,6 +1209,12 @@ extern "C" int bz2hip_stitch_device(bz2hip_ctx *c, int level, uint32_t nseg,
 extern "C" int bz2hip_stream_begin(bz2hip_ctx *c, int level) {
     if (!c) return BZ2HIP_E_PARAM;
     if (level < 1 || level > 9) return fail(c, BZ2HIP_E_PARAM, "Invalid BZip2 block size");
+    stream_drain(c); // what an abandoned stream still had in flight
+    c->s_async = c->peers.empty() && !c->stream_sync;
+    c->sw.cur = 0;
+    c->sw.fill = 0;
+    c->sw.carry = 0;
+    c->sw.err = 0;
     c->s_level = level;
     c->s_open = true;
     c->s_finished = false;
@@ -1254,10 +1283,202 @@ static int stream_flush(bz2hip_ctx *c, bool final) {
     });
 }
 
+// ---- the asynchronous path (single-device contexts)
+// One chunk on the worker thread: [carried bytes | the chunk] -> complete blocks (all of it when
+// final) -> s_out.  The bytes of an incomplete last block stay in HBM, at the front of sw.d_in (a buffer of the
+// stream's own: other calls on the context between two writes leave it alone).
+static void stream_job(bz2hip_ctx *c, const bz2hip_ctx::StreamWorker::Job &job) {
+    auto &W = c->sw;
+    const auto t_job = std::chrono::steady_clock::now();
+    const size_t n = W.carry + job.n;
+    const size_t bound = bz2hip_compress_bound(n) + 16;
+    if (W.d_in_cap < n) {
+        // grow the device input buffer, keeping the carried bytes
+        const size_t want = n + (n >> 2) + ((size_t)c->s_level * 200000u);
+        u8 *nin = nullptr;
+        HIPCHK(hipMalloc((void **)&nin, want + 64));
+        if (W.carry) HIPCHK(hipMemcpy(nin, W.d_in, W.carry, hipMemcpyDeviceToDevice));
+        if (W.d_in) (void)hipFree(W.d_in);
+        W.d_in = nin;
+        W.d_in_cap = want;
+    }
+    {
+        // size the output staging and the batch workspace for the largest job this stream can hand
+        // over, once, instead of growing them job by job (a few ms of hipFree / hipMalloc each time)
+        const size_t nmax = std::max(n, W.pin_cap + (size_t)c->s_level * 200000u);
+        ensure_staging(c, 0, std::max(bound, bz2hip_compress_bound(nmax) + 16));
+        const u32 bs = (u32)c->s_level * 100000u;
+        const int est = (int)std::min<size_t>(nmax / (bs - 4) + 1, (size_t)batch_cap(c));
+        if (!c->fixed_ws) ensure_batch(c, c->s_level, est);
+    }
+    const auto t_a = std::chrono::steady_clock::now();
+    if (job.n) HIPCHK(hipMemcpyAsync(W.d_in + W.carry, W.pin[job.buf], job.n, hipMemcpyHostToDevice, c->stream));
+    const size_t zlen = bound & ~(size_t)3;
+    HIPCHK(hipMemsetAsync(c->h_out, 0, zlen, c->stream));
+    u64 bitpos = (u64)c->s_bitcnt;
+    u32 scrc = c->s_stream_crc;
+    const size_t used = compress_core(c, W.d_in, n, c->s_level, c->h_out, zlen, &bitpos, &scrc, false, job.final);
+    c->s_stream_crc = scrc;
+    const auto t_b = std::chrono::steady_clock::now();
+    if (job.final || used > 0) {
+        // download into a page-locked buffer kept by the stream (a fresh pageable vector of this
+        // size costs more in page faults than the transfer takes)
+        const size_t tlen = (size_t)((bitpos + 7) / 8);
+        if (W.pin_out_cap < tlen + 8) {
+            if (W.pin_out) (void)hipHostFree(W.pin_out);
+            W.pin_out = nullptr;
+            W.pin_out_cap = 0;
+            HIPCHK(hipHostMalloc((void **)&W.pin_out, c->h_out_cap + 64, hipHostMallocDefault));
+            W.pin_out_cap = c->h_out_cap + 64;
+        }
+        u8 *tmp = W.pin_out;
+        if (tlen) HIPCHK(hipMemcpy(tmp, c->h_out, tlen, hipMemcpyDeviceToHost));
+        if (c->s_bitcnt > 0 && tlen) tmp[0] |= (u8)c->s_bitbuf;
+        const size_t full = job.final ? tlen : (size_t)(bitpos / 8);
+        {
+            std::lock_guard<std::mutex> lk(W.mu);
+            c->s_out.insert(c->s_out.end(), tmp, tmp + full);
+        }
+        if (!job.final) {
+            c->s_bitcnt = (int)(bitpos & 7);
+            c->s_bitbuf = c->s_bitcnt ? tmp[full] : 0;
+        } else {
+            c->s_bitcnt = 0;
+            c->s_bitbuf = 0;
+        }
+    }
+    if (c->debug)
+        fprintf(stderr, "[bz2hip] stream job: %zu carried + %zu new bytes, %zu used, final %d, %.2f ms (set-up %.2f, compress %.2f)\n",
+                W.carry, job.n, used, (int)job.final,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_job).count(),
+                std::chrono::duration<double, std::milli>(t_a - t_job).count(),
+                std::chrono::duration<double, std::milli>(t_b - t_a).count());
+    const size_t rest = n - used;
+    if (rest && used) {
+        if (used >= rest) {
+            HIPCHK(hipMemcpyAsync(W.d_in, W.d_in + used, rest, hipMemcpyDeviceToDevice, c->stream));
+        } else { // the ranges overlap: through the output buffer (bound >= n > rest)
+            HIPCHK(hipMemcpyAsync(c->h_out, W.d_in + used, rest, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(W.d_in, c->h_out, rest, hipMemcpyDeviceToDevice, c->stream));
+        }
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    W.carry = job.final ? 0 : rest;
+}
+
+static void stream_worker(bz2hip_ctx *c) {
+    auto &W = c->sw;
+    (void)hipSetDevice(c->device);
+    for (;;) {
+        bz2hip_ctx::StreamWorker::Job job;
+        bool skip;
+        {
+            std::unique_lock<std::mutex> lk(W.mu);
+            W.cv.wait(lk, [&] { return W.quit || !W.q.empty(); });
+            if (W.q.empty()) return;
+            job = W.q.front();
+            W.q.pop_front();
+            skip = W.err != 0; // after an error the rest of the stream is dropped
+        }
+        int rc = BZ2HIP_OK;
+        std::string msg;
+        if (!skip) {
+            try {
+                stream_job(c, job);
+            } catch (const HipError &e) {
+                rc = e.code;
+                msg = e.what();
+                (void)hipGetLastError();
+            } catch (const std::bad_alloc &) {
+                rc = BZ2HIP_E_NOMEM;
+                msg = "host allocation failed";
+            } catch (const std::exception &e) {
+                rc = BZ2HIP_E_HIP;
+                msg = e.what();
+            }
+        }
+        {
+            std::lock_guard<std::mutex> lk(W.mu);
+            if (rc != BZ2HIP_OK && !W.err) {
+                W.err = rc;
+                W.errmsg = msg;
+            }
+            W.busy[job.buf] = false;
+            W.active--;
+        }
+        W.cv.notify_all();
+    }
+}
+
+// hands the buffer being filled to the worker and takes the other one (waits until it is free)
+static void stream_submit(bz2hip_ctx *c, bool final) {
+    auto &W = c->sw;
+    std::unique_lock<std::mutex> lk(W.mu);
+    if (!W.running) {
+        W.quit = false;
+        W.th = std::thread(stream_worker, c);
+        W.running = true;
+    }
+    W.busy[W.cur] = true;
+    W.q.push_back({W.cur, W.fill, final});
+    W.active++;
+    W.cv.notify_all();
+    W.cur ^= 1;
+    W.fill = 0;
+    W.cv.wait(lk, [&] { return !W.busy[W.cur]; });
+}
+
+static int stream_error(bz2hip_ctx *c) {
+    std::lock_guard<std::mutex> lk(c->sw.mu);
+    if (!c->sw.err) return BZ2HIP_OK;
+    c->err = c->sw.errmsg;
+    return c->sw.err;
+}
+
+static int stream_write_async(bz2hip_ctx *c, const uint8_t *p, size_t n) {
+    auto &W = c->sw;
+    if (int rc = stream_error(c)) return rc;
+    // Hand-over rule: a buffer holds two chunks; it goes to the worker when it is full, or as soon
+    // as the worker is idle and half a chunk has gathered -- so the first batch starts early and
+    // later ones are as large as the GPU's pace allows (large batches compress faster).
+    const size_t cap = 2 * c->stream_chunk, piece = (size_t)4 << 20;
+    const size_t least = c->stream_least ? std::min(c->stream_least, cap) : c->stream_chunk / 2;
+    if (W.pin_cap != cap) {
+        // (no job is in flight here: the buffers are only sized between streams or at the first write)
+        if (hipSetDevice(c->device) != hipSuccess) return fail(c, BZ2HIP_E_HIP, "hipSetDevice failed");
+        for (int k = 0; k < 2; k++) {
+            if (W.pin[k]) (void)hipHostFree(W.pin[k]);
+            W.pin[k] = nullptr;
+        }
+        W.pin_cap = 0;
+        for (int k = 0; k < 2; k++)
+            if (hipHostMalloc((void **)&W.pin[k], cap, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(c, BZ2HIP_E_NOMEM, "page-locked allocation failed");
+            }
+        W.pin_cap = cap;
+    }
+    while (n) {
+        const size_t k = std::min(std::min(W.pin_cap - W.fill, n), piece);
+        memcpy(W.pin[W.cur] + W.fill, p, k);
+        W.fill += k;
+        p += k;
+        n -= k;
+        bool go = W.fill == W.pin_cap;
+        if (!go && W.fill >= least) {
+            std::lock_guard<std::mutex> lk(W.mu);
+            go = W.active == 0;
+        }
+        if (go) stream_submit(c, false);
+    }
+    return stream_error(c);
+}
+
 extern "C" int bz2hip_stream_write(bz2hip_ctx *c, const uint8_t *p, size_t n) {
     if (!c) return BZ2HIP_E_PARAM;
     if (!c->s_open || c->s_finished) return fail(c, BZ2HIP_E_STATE, "Write beyond end of stream");
     if (n && !p) return fail(c, BZ2HIP_E_PARAM, "null pointer");
+    if (c->s_async) return stream_write_async(c, p, n);
     try {
         c->s_in.insert(c->s_in.end(), p, p + n);
     } catch (const std::bad_alloc &) {
@@ -1271,6 +1492,14 @@ extern "C" int bz2hip_stream_finish(bz2hip_ctx *c) {
     if (!c) return BZ2HIP_E_PARAM;
     if (!c->s_open) return fail(c, BZ2HIP_E_STATE, "stream not open");
     if (c->s_finished) return BZ2HIP_OK; // finish() is idempotent (S/BZip2OutputStream.swift:151)
+    if (c->s_async) {
+        if (int rc0 = stream_error(c)) return rc0;
+        stream_submit(c, true);
+        stream_drain(c);
+        const int rc1 = stream_error(c);
+        if (rc1 == BZ2HIP_OK) c->s_finished = true;
+        return rc1;
+    }
     int rc = stream_flush(c, true);
     if (rc == BZ2HIP_OK) c->s_finished = true;
     return rc;
@@ -1278,6 +1507,7 @@ extern "C" int bz2hip_stream_finish(bz2hip_ctx *c) {
 
 extern "C" int bz2hip_stream_read(bz2hip_ctx *c, uint8_t *out, size_t cap, size_t *produced) {
     if (!c || !produced) return BZ2HIP_E_PARAM;
+    std::lock_guard<std::mutex> lk(c->sw.mu);
     size_t avail = c->s_out.size() - c->s_out_pos;
     size_t k = std::min(avail, cap);
     if (k) memcpy(out, c->s_out.data() + c->s_out_pos, k);
@@ -1291,7 +1521,9 @@ extern "C" int bz2hip_stream_read(bz2hip_ctx *c, uint8_t *out, size_t cap, size_
 }
 
 extern "C" size_t bz2hip_stream_pending(const bz2hip_ctx *c) {
-    return c ? c->s_out.size() - c->s_out_pos : 0;
+    if (!c) return 0;
+    std::lock_guard<std::mutex> lk(const_cast<bz2hip_ctx *>(c)->sw.mu);
+    return c->s_out.size() - c->s_out_pos;
 }
 
 // ------------------------------------------------------------------ stage entry points

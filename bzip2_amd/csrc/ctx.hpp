@@ -3,7 +3,11 @@
 #include "common.hpp"
 #include "../../include/bz2hip.h"
 
+#include <condition_variable>
+#include <deque>
 #include <map>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -155,6 +159,8 @@ struct bz2hip_ctx {
     bool radix_stage = true;  // BZ2HIP_RADIX_STAGE: order the tile by digit in LDS before the stores
     u32 radix_bits = 8;      // BZ2HIP_RADIX_BITS: digit width of the LSD passes (8: 5 passes, 10: 4 passes)
     size_t stream_chunk = (size_t)64 << 20; // BZ2HIP_STREAM_CHUNK_MIB: streaming flush threshold per GPU
+    size_t stream_least = 0;                // BZ2HIP_STREAM_LEAST_MIB: hand-over threshold while the worker is idle (0: half a chunk)
+    bool stream_sync = false;               // BZ2HIP_STREAM_SYNC: compress inside bz2hip_stream_write (experiments)
     u64 dec_pass_bytes = 0xfffffff0ull;     // BZ2HIP_DEC_PASS_MIB (tests): decoded bytes written per pass (u32 offsets)
     // decoder workspace, kept between calls (one region, grown on demand)
     size_t dec_consumed = 0;   // bytes of the input the last successfully decoded stream occupied
@@ -230,6 +236,34 @@ struct bz2hip_ctx {
     u32 s_stream_crc = 0;
     u32 s_bitbuf = 0;          // pending partial byte (left aligned in low 8 bits)
     int s_bitcnt = 0;
+    // Streaming on a single-device context is asynchronous: bz2hip_stream_write fills one of two
+    // page-locked chunk buffers and hands full ones to a worker thread, which uploads, compresses and
+    // appends to s_out while the caller fills the other buffer (the reference's write() also returns
+    // before a block is closed, S/BZip2OutputStream.swift:85-104).  sw.mu guards the job queue, s_out /
+    // s_out_pos and the error slot.  Between bz2hip_stream_begin and the end of bz2hip_stream_finish
+    // the device side of the context belongs to the worker.
+    struct StreamWorker {
+        struct Job { int buf; size_t n; bool final; };
+        std::thread th;
+        std::mutex mu;
+        std::condition_variable cv;
+        std::deque<Job> q;
+        bool busy[2] = {false, false}; // chunk buffer handed over and not yet consumed
+        bool running = false, quit = false;
+        int active = 0;                // jobs queued or in progress
+        int err = 0;                   // first error of the stream (reported by the next call)
+        std::string errmsg;
+        u8 *pin[2] = {nullptr, nullptr};
+        size_t pin_cap = 0;
+        int cur = 0;                   // caller: the buffer being filled, and its fill
+        size_t fill = 0;
+        u8 *pin_out = nullptr;         // worker: page-locked landing buffer of a job's output
+        size_t pin_out_cap = 0;
+        u8 *d_in = nullptr;            // worker: device input buffer of the stream
+        size_t d_in_cap = 0;
+        size_t carry = 0;              // worker: bytes of an incomplete last block kept at the front of d_in
+    } sw;
+    bool s_async = false;
 
     hipEvent_t get_event() {
         if (!ev_pool.empty()) {

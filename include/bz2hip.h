@@ -168,7 +168,16 @@ int bz2hip_stitch(int level, uint32_t nseg, const uint8_t *const *seg_bits,
  * bz2hip_stream_finish = finish()                      :149-161
  * bz2hip_stream_read   drains compressed bytes in stream order (the bytes the reference would
  *                        have passed to java.io.OutputStream.write, S/BZip2BitOutputStream.swift:58,93)
- * Writing after finish returns BZ2HIP_E_STATE ("Write beyond end of stream", :69-71,89-91). */
+ * Writing after finish returns BZ2HIP_E_STATE ("Write beyond end of stream", :69-71,89-91).
+ * On a single-device context the stream is asynchronous, as the reference's write() is for its
+ * caller (it returns once the bytes are taken, blocks are closed later): write copies into one
+ * of two page-locked buffers (2 x 64 MiB each) and a worker thread of the context uploads,
+ * compresses and queues the output while the caller fills the other buffer; a buffer is handed
+ * over when it is full, or when the worker is idle and 32 MiB have gathered.  Compressed bytes
+ * therefore become readable some time after the write that completed their block; after
+ * bz2hip_stream_finish has returned all of them are.  An error of the worker is reported by the
+ * next write / finish.  Any other call on the context while a stream is open first waits for the
+ * worker and leaves the stream intact.  Contexts with a device list compress inside write / finish. */
 int bz2hip_stream_begin(bz2hip_ctx *ctx, int level);
 int bz2hip_stream_write(bz2hip_ctx *ctx, const uint8_t *p, size_t n);
 int bz2hip_stream_finish(bz2hip_ctx *ctx);

@@ -271,6 +271,53 @@ def test_streaming_api(ctx, orc):
     assert ctx.stream_read() == bytes.fromhex("425a683917724538509000000000")
 
 
+def test_streaming_api_small_chunks(orc, monkeypatch):
+    """The asynchronous stream path with 1 MiB chunks: many hand-overs to the worker, blocks that
+    swallow several chunks (long runs: nothing to emit for a while, the carried bytes grow), carried
+    bytes longer than what a chunk consumed (overlapping move), reads interleaved with writes, a
+    second stream on the same context, and an abandoned stream."""
+    from bzip2_amd import Context
+    monkeypatch.setenv("BZ2HIP_STREAM_CHUNK_MIB", "1")
+    c = Context(device=0)
+    rng = np.random.default_rng(5)
+    d1 = np.concatenate((corpus.mixed(3, 41, seg_bytes=700001), np.zeros(9_000_000, dtype=np.uint8),
+                         corpus.mixed(2, 42, seg_bytes=1_300_000), np.full(2_500_000, 7, dtype=np.uint8),
+                         corpus.mixed(4, 43, seg_bytes=300_000)))
+    d2 = corpus.mixed(5, 44, seg_bytes=1 << 20)
+    for d, level in ((d1, 9), (d2, 1), (d1[:5], 5), (d1[:0], 9)):
+        want, _ = orc.compress(d, level)
+        c.stream_begin(level)
+        out, pos = b"", 0
+        while pos < d.size:
+            k = int(rng.integers(1, 3_000_000))
+            c.stream_write(d[pos:pos + k])
+            pos += k
+            if rng.integers(2):
+                out += c.stream_read(1 << 22)
+        c.stream_finish()
+        while c.stream_pending():
+            out += c.stream_read(1 << 22)
+        assert out == want, (d.size, level)
+    # a stream that is never finished does not leak into the next one
+    c.stream_begin(9)
+    c.stream_write(d2[:3_000_000])
+    c.stream_begin(9)
+    c.stream_write(d2[:10])
+    c.stream_finish()
+    assert c.stream_read() == orc.compress(d2[:10], 9)[0]
+    # other calls on the context between two writes wait for the worker and leave the stream alone
+    c.stream_begin(9)
+    c.stream_write(d2[:2_500_000])
+    assert c.compress(d2[:1000], 9) == orc.compress(d2[:1000], 9)[0]
+    c.stream_write(d2[2_500_000:])
+    c.stream_finish()
+    out = b""
+    while c.stream_pending():
+        out += c.stream_read(1 << 22)
+    assert out == orc.compress(d2, 9)[0]
+    c.close()
+
+
 def _sharded_on_one_gpu(ctx, data, level, world, lookahead=None, device_stitch=False):
     """every "rank" of the multi-GPU path, one after the other on this GPU, through the C ABI"""
     import torch
