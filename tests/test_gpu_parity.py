@@ -610,6 +610,24 @@ def test_failed_allocation_leaves_the_context_usable():
         # same level, small input: must allocate a small batch and work (not reuse stale capacities)
         small = corpus.text(250000, 5)
         assert bz2.decompress(c.compress(small, 1)) == small.tobytes()
+        # the stream worker fails the same way (1 GB left, its batch workspace needs more): the error
+        # comes back from write or finish, and the context goes on working
+        free2, _ = torch.cuda.mem_get_info()
+        hog2 = torch.empty(max(free2 - (1 << 30), 1 << 20), dtype=torch.uint8, device="cuda")
+        c.stream_begin(9)
+        with pytest.raises(bzip2_amd.BZ2HipError) as e2:
+            c.stream_write(np.zeros(40 << 20, dtype=np.uint8))
+            c.stream_finish()
+        assert e2.value.code == -2
+        del hog2
+        torch.cuda.empty_cache()
+        c.stream_begin(1)
+        c.stream_write(small)
+        c.stream_finish()
+        got = b""
+        while c.stream_pending():
+            got += c.stream_read()
+        assert bz2.decompress(got) == small.tobytes()
         del hog
         torch.cuda.empty_cache()
         k = c.compress_device(d_in.data_ptr(), 64 << 20, 1, d_out.data_ptr(), cap)
