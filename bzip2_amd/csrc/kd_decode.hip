@@ -173,8 +173,9 @@ __device__ __forceinline__ u32 kd_chain(u32 ment, u32 &off, u32 &n, u32 lim, u64
 __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nbytes,
                                                const u64 *__restrict__ cand, u32 block_size, u32 S,
                                                u8 *__restrict__ bwt, u32 *__restrict__ meta,
-                                               u8 *__restrict__ symmap_out) {
-    const u32 b = blockIdx.x;
+                                               u8 *__restrict__ symmap_out,
+                                               const u32 *__restrict__ list) {
+    const u32 b = list[blockIdx.x]; // candidate slot of the batch
     const int lane = lane_id();
     const int wv = wave_id();
     __shared__ u32 win[KD_WIN / 4];
@@ -697,12 +698,12 @@ __device__ __forceinline__ u32 kd_imtf_row(u32 &L, u32 p, bool valid) {
 __global__ __launch_bounds__(256) void kd_imtf_perm(const u8 *__restrict__ bwt, const u32 *__restrict__ slot,
                                                     const u32 *__restrict__ nArr, u32 S, u32 CH,
                                                     u8 *__restrict__ perm) {
-    const u32 k = blockIdx.y, n = nArr[k];
+    const u32 k = slot[blockIdx.y], n = nArr[k];
     const int lane = lane_id();
     const u32 c = blockIdx.x * 4u + (u32)wave_id();
     const u32 base = c * KD_MCHUNK;
     if (base >= n) return;
-    const u8 *pos = bwt + (size_t)slot[k] * S;
+    const u8 *pos = bwt + (size_t)k * S;
     u8 rowv[KD_MCHUNK / 64];
 #pragma unroll
     for (int r = 0; r < KD_MCHUNK / 64; r++) rowv[r] = pos[min(base + r * 64 + lane, n - 1)];
@@ -721,11 +722,11 @@ __global__ __launch_bounds__(256) void kd_imtf_perm(const u8 *__restrict__ bwt, 
 __global__ __launch_bounds__(64) void kd_imtf_compose(const u32 *__restrict__ slot, const u32 *__restrict__ nArr,
                                                       const u8 *__restrict__ symmap, u32 CH,
                                                       u8 *__restrict__ perm) {
-    const u32 k = blockIdx.x, n = nArr[k];
+    const u32 k = slot[blockIdx.x], n = nArr[k];
     const int lane = lane_id();
     const u32 chunks = (n + KD_MCHUNK - 1) / KD_MCHUNK;
     __shared__ __attribute__((aligned(16))) u8 cur[256];
-    ((u32 *)cur)[lane] = ((const u32 *)(symmap + (size_t)slot[k] * 256))[lane];
+    ((u32 *)cur)[lane] = ((const u32 *)(symmap + (size_t)k * 256))[lane];
     __syncthreads();
     u32 *pw = (u32 *)(perm + (size_t)k * CH * 256);
     // the permutations do not depend on the walk: fetch them 8 chunks at a time
@@ -752,12 +753,12 @@ __global__ __launch_bounds__(64) void kd_imtf_compose(const u32 *__restrict__ sl
 __global__ __launch_bounds__(256) void kd_imtf_apply(u8 *__restrict__ bwt, const u32 *__restrict__ slot,
                                                      const u32 *__restrict__ nArr, u32 S, u32 CH,
                                                      const u8 *__restrict__ perm) {
-    const u32 k = blockIdx.y, n = nArr[k];
+    const u32 k = slot[blockIdx.y], n = nArr[k];
     const int lane = lane_id();
     const u32 c = blockIdx.x * 4u + (u32)wave_id();
     const u32 base = c * KD_MCHUNK;
     if (base >= n) return;
-    u8 *pos = bwt + (size_t)slot[k] * S;
+    u8 *pos = bwt + (size_t)k * S;
     u8 rowv[KD_MCHUNK / 64];
 #pragma unroll
     for (int r = 0; r < KD_MCHUNK / 64; r++) rowv[r] = pos[min(base + r * 64 + lane, n - 1)];
@@ -772,7 +773,8 @@ __global__ __launch_bounds__(256) void kd_imtf_apply(u8 *__restrict__ bwt, const
 }
 
 // ------------------------------------------------------------------ inverse BWT
-// per-block list of the slots to work on: slot[k] = candidate index, nArr / orig per chain block
+// Every per-block array of the stages below is indexed by the candidate's slot in the batch; a launch
+// works on a list of slots (`slot` / `list`), nArr / origArr come from kd_set_meta
 #define KD_MPARTS 8 // the counting sort of a block runs as 8 waves over 8 index ranges
 __device__ __forceinline__ u32 kd_part_len(u32 n) { return (((n + KD_MPARTS - 1) / KD_MPARTS) + 255u) & ~255u; }
 
@@ -780,12 +782,12 @@ __device__ __forceinline__ u32 kd_part_len(u32 n) { return (((n + KD_MPARTS - 1)
 __global__ __launch_bounds__(256) void kd_hist(const u8 *__restrict__ bwt, const u32 *__restrict__ slot,
                                                const u32 *__restrict__ nArr, u32 S,
                                                u32 *__restrict__ base) {
-    const u32 b = blockIdx.x;
+    const u32 b = slot[blockIdx.x];
     __shared__ u32 h[KD_MPARTS][256];
     __shared__ u32 sm[8];
     for (int q = 0; q < KD_MPARTS; q++) h[q][threadIdx.x] = 0;
     __syncthreads();
-    const u8 *p = bwt + (size_t)slot[b] * S;
+    const u8 *p = bwt + (size_t)b * S;
     const u32 n = nArr[b];
     const u32 pl = kd_part_len(n);
     for (u32 i = threadIdx.x; i < n; i += 256) atomicAdd(&h[i / pl][p[i]], 1u);
@@ -805,13 +807,13 @@ __global__ __launch_bounds__(256) void kd_hist(const u8 *__restrict__ bwt, const
 __global__ __launch_bounds__(64) void kd_merge(const u8 *__restrict__ bwt, const u32 *__restrict__ slot,
                                                const u32 *__restrict__ nArr, u32 S,
                                                const u32 *__restrict__ base, u32 *__restrict__ merged) {
-    const u32 b = blockIdx.y, part = blockIdx.x;
+    const u32 b = slot[blockIdx.y], part = blockIdx.x;
     const int lane = lane_id();
     __shared__ u32 run[256];
     for (int q = lane; q < 256; q += 64) run[q] = base[((size_t)b * KD_MPARTS + part) * 256 + q];
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
-    const u8 *p = bwt + (size_t)slot[b] * S;
+    const u8 *p = bwt + (size_t)b * S;
     u32 *mg = merged + (size_t)b * S;
     const u32 nn = nArr[b], pl = kd_part_len(nn);
     const u32 n = min(nn, (part + 1u) * pl); // this part: [part * pl, n)
@@ -856,8 +858,8 @@ __device__ __forceinline__ u32 kd_ruler_id(u32 x, u32 orig, u32 NR) {
 __global__ __launch_bounds__(256) void kd_walk_a(const u32 *__restrict__ merged,
                                                  const u32 *__restrict__ nArr,
                                                  const u32 *__restrict__ origArr, u32 S, u32 RS,
-                                                 uint2 *__restrict__ rinfo) {
-    const u32 b = blockIdx.y;
+                                                 uint2 *__restrict__ rinfo, const u32 *__restrict__ list) {
+    const u32 b = list[blockIdx.y];
     const u32 n = nArr[b], orig = origArr[b];
     if (n == 0) return;
     const u32 NR = (n + KD_RULER - 1) / KD_RULER;
@@ -881,9 +883,11 @@ __global__ __launch_bounds__(256) void kd_walk_a(const u32 *__restrict__ merged,
 // b) one lane per block: the ruler chain from the origin; visits[k] = {ruler id, output offset}
 __global__ void kd_walk_b(const u32 *__restrict__ nArr, const u32 *__restrict__ origArr, u32 RS,
                           const uint2 *__restrict__ rinfo, uint2 *__restrict__ visits,
-                          u32 *__restrict__ nvis, u32 *__restrict__ cyc, u32 nb) {
-    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb) return;
+                          u32 *__restrict__ nvis, u32 *__restrict__ cyc, u32 nb,
+                          const u32 *__restrict__ list) {
+    const u32 bi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bi >= nb) return;
+    const u32 b = list[bi];
     const u32 n = nArr[b], orig = origArr[b];
     if (n == 0) { nvis[b] = 0; cyc[b] = 0; return; }
     const u32 NR = (n + KD_RULER - 1) / KD_RULER;
@@ -908,8 +912,9 @@ __global__ __launch_bounds__(256) void kd_walk_c(const u32 *__restrict__ merged,
                                                  const uint2 *__restrict__ rinfo,
                                                  const uint2 *__restrict__ visits,
                                                  const u32 *__restrict__ nvis,
-                                                 const u32 *__restrict__ cyc, u8 *__restrict__ tt) {
-    const u32 b = blockIdx.y;
+                                                 const u32 *__restrict__ cyc, u8 *__restrict__ tt,
+                                                 const u32 *__restrict__ list) {
+    const u32 b = list[blockIdx.y];
     const u32 k = blockIdx.x * 256 + threadIdx.x;
     if (k >= nvis[b]) return;
     const u32 n = nArr[b], orig = origArr[b];
@@ -929,8 +934,8 @@ __global__ __launch_bounds__(256) void kd_walk_c(const u32 *__restrict__ merged,
 
 __global__ __launch_bounds__(256) void kd_cycfill(const u32 *__restrict__ nArr,
                                                   const u32 *__restrict__ cyc, u32 S,
-                                                  u8 *__restrict__ tt) {
-    const u32 b = blockIdx.y;
+                                                  u8 *__restrict__ tt, const u32 *__restrict__ list) {
+    const u32 b = list[blockIdx.y];
     const u32 n = nArr[b], c = cyc[b];
     if (c == 0 || c >= n) return;
     u8 *o = tt + (size_t)b * S;
@@ -1022,8 +1027,9 @@ __device__ __forceinline__ u32 kd_unrle_range(const u8 *__restrict__ p, u32 a, u
 
 // piece k of a block starts at the first run head at or after k * ceil(n / KD_SEGS)
 __global__ __launch_bounds__(64) void kd_segs(const u8 *__restrict__ tt, const u32 *__restrict__ nArr,
-                                              u32 S, u32 *__restrict__ segstart) {
-    const u32 b = blockIdx.y, k = blockIdx.x;
+                                              u32 S, u32 *__restrict__ segstart,
+                                              const u32 *__restrict__ list) {
+    const u32 b = list[blockIdx.y], k = blockIdx.x;
     const u32 n = nArr[b];
     const u8 *p = tt + (size_t)b * S;
     u32 pos = (u32)(((u64)k * n + KD_SEGS - 1) / KD_SEGS);
@@ -1048,8 +1054,9 @@ __global__ __launch_bounds__(64) void kd_segs(const u8 *__restrict__ tt, const u
 __global__ __launch_bounds__(64) void kd_unrle_count(const u8 *__restrict__ tt,
                                                      const u32 *__restrict__ nArr, u32 S,
                                                      const u32 *__restrict__ segstart,
-                                                     u32 *__restrict__ segres) {
-    const u32 b = blockIdx.y, k = blockIdx.x;
+                                                     u32 *__restrict__ segres,
+                                                     const u32 *__restrict__ list) {
+    const u32 b = list[blockIdx.y], k = blockIdx.x;
     const u32 n = nArr[b];
     const u8 *p = tt + (size_t)b * S;
     const u32 a = segstart[(size_t)b * (KD_SEGS + 1) + k], e = segstart[(size_t)b * (KD_SEGS + 1) + k + 1];
@@ -1067,9 +1074,11 @@ __global__ __launch_bounds__(64) void kd_unrle_count(const u8 *__restrict__ tt,
 
 // per block: entry state and output offset of every piece; the block's length and flags
 __global__ void kd_unrle_resolve(const u32 *__restrict__ segres, u32 *__restrict__ segin,
-                                 u32 *__restrict__ outlen, u32 *__restrict__ flags, u32 nb) {
-    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb) return;
+                                 u32 *__restrict__ outlen, u32 *__restrict__ flags, u32 nb,
+                                 const u32 *__restrict__ list) {
+    const u32 bi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bi >= nb) return;
+    const u32 b = list[bi];
     u32 st = 0, off = 0;
     bool ov = false;
     for (u32 k = 0; k < KD_SEGS; k++) {
@@ -1090,15 +1099,31 @@ __global__ __launch_bounds__(64) void kd_unrle_write(const u8 *__restrict__ tt,
                                                      const u32 *__restrict__ segstart,
                                                      const u32 *__restrict__ segin,
                                                      const u32 *__restrict__ outbase,
-                                                     u8 *__restrict__ out) {
-    const u32 b = blockIdx.y, k = blockIdx.x;
+                                                     u8 *__restrict__ out,
+                                                     const u32 *__restrict__ order) {
+    // blockIdx.y = position in the block chain (output order); order[] = its candidate slot
+    const u32 b = order[blockIdx.y], k = blockIdx.x;
     const u32 n = nArr[b];
     const u8 *p = tt + (size_t)b * S;
     const u32 a = segstart[(size_t)b * (KD_SEGS + 1) + k], e = segstart[(size_t)b * (KD_SEGS + 1) + k + 1];
     u32 off = segin[((size_t)b * KD_SEGS + k) * 2 + 1];
     bool ov = false;
     (void)kd_unrle_range<true>(p, a, e, n, S, segin[((size_t)b * KD_SEGS + k) * 2], off, ov,
-                               out + outbase[b]);
+                               out + outbase[blockIdx.y]);
+}
+
+// What the stages after kd_huff need of a candidate, from its meta words: length and origin pointer
+// (0 / 0 for a candidate that did not decode, or whose pointer is invalid: every stage skips it).
+__global__ void kd_set_meta(const u32 *__restrict__ list, u32 count, const u32 *__restrict__ meta,
+                            u32 block_size, u32 *__restrict__ nArr, u32 *__restrict__ origArr) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const u32 b = list[i];
+    const u32 *mt = meta + (size_t)b * KM_WORDS;
+    u32 n = mt[KM_N], orig = mt[KM_ORIG];
+    if (mt[KM_STATUS] != KS_OK || n > block_size || orig >= n) { n = 0; orig = 0; }
+    nArr[b] = n;
+    origArr[b] = orig;
 }
 
 // ------------------------------------------------------------------ host driver
@@ -1163,6 +1188,7 @@ int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size
     u8 *d_bwt = nullptr, *d_tt = nullptr, *d_symmap = nullptr, *d_perm = nullptr;
     const u32 CH = S / KD_MCHUNK + 1; // chunks of the inverse MTF per block slot
     u32 *d_meta = nullptr, *d_slot = nullptr, *d_n = nullptr, *d_orig = nullptr, *d_base = nullptr, *d_merged = nullptr;
+    u32 *d_order = nullptr;
     uint2 *d_rinfo = nullptr, *d_visits = nullptr;
     u32 *d_nvis = nullptr, *d_cyc = nullptr, *d_outlen = nullptr, *d_flags = nullptr, *d_outbase = nullptr, *d_crc = nullptr;
     u32 *d_segstart = nullptr, *d_segres = nullptr, *d_segin = nullptr, *d_cagg = nullptr;
@@ -1175,7 +1201,7 @@ int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size
         d_meta = A.get<u32>((size_t)NB * KM_WORDS);
         d_symmap = A.get<u8>((size_t)NB * 256);
         d_perm = A.get<u8>((size_t)NB * CH * 256);
-        d_slot = A.get<u32>(NB); d_n = A.get<u32>(NB); d_orig = A.get<u32>(NB);
+        d_slot = A.get<u32>(NB); d_n = A.get<u32>(NB); d_orig = A.get<u32>(NB); d_order = A.get<u32>(NB);
         d_base = A.get<u32>((size_t)NB * KD_MPARTS * 256);
         d_merged = A.get<u32>((size_t)NB * S);
         d_rinfo = A.get<uint2>((size_t)NB * RS); d_visits = A.get<uint2>((size_t)NB * RS);
@@ -1227,10 +1253,85 @@ int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size
         if (it == cand.end() || *it != cur) break; // not a block: end marker or garbage, below
         const u32 i0 = (u32)(it - cand.begin());
         const u32 nbatch = std::min<u32>(ncand - i0, NB);
-        kd_huff<<<nbatch, 128, 0, st>>>(d_in, nbytes, d_cand + i0, block_size, S, d_bwt, d_meta, d_symmap);
-        KCHECK();
+        // The Huffman stage lasts as long as its slowest block (the chain of a block is serial), and
+        // that is a block with many compressed bits.  The candidates are therefore grouped by the
+        // distance to the next magic (longest first), each group on a stream of its own with
+        // everything that follows per block -- inverse MTF, inverse BWT, the counting half of the
+        // run-length decoding -- so the later stages of the short blocks run under the Huffman stage
+        // of the long ones.  Nothing here needs the host: a candidate's length and origin pointer go
+        // from its meta words to the stages on the device (a candidate off the chain is decoded for
+        // nothing, as before).  Only the chain walk and the placement of the output wait for all.
+        // Two groups on the context's two streams: a process has few hardware queues (4 here), and
+        // two streams that share one run their groups one after the other -- with four groups the
+        // fourth Huffman launch waited behind the whole chain of the third (151 ms instead of 109).
+        constexpr u32 KD_GROUPS = 2;
+        std::vector<u32> glist;
+        glist.reserve(nbatch);
+        u32 gbeg[KD_GROUPS + 1];
+        {
+            std::vector<u64> span(nbatch);
+            u64 smax = 1;
+            for (u32 ci = 0; ci < nbatch; ci++) {
+                const u64 nxt = (i0 + ci + 1 < ncand) ? cand[i0 + ci + 1] : total_bits;
+                span[ci] = nxt - cand[i0 + ci];
+                smax = std::max(smax, span[ci]);
+            }
+            for (u32 g = 0; g < KD_GROUPS; g++) {
+                gbeg[g] = (u32)glist.size();
+                const u32 want = KD_GROUPS - 1 - g; // longest first
+                for (u32 ci = 0; ci < nbatch; ci++)
+                    if ((u32)std::min<u64>(KD_GROUPS - 1, span[ci] * KD_GROUPS / (smax + 1)) == want) glist.push_back(ci);
+            }
+            gbeg[KD_GROUPS] = (u32)glist.size();
+        }
+        HIPCHK(hipMemcpyAsync(d_slot, glist.data(), nbatch * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipEventRecord(c->ev_fork, st)); // also orders the candidate upload before the other streams
+        hipStream_t gstream[KD_GROUPS] = {st, c->stream_other};
+        for (u32 g = 0; g < KD_GROUPS; g++) {
+            const u32 cnt = gbeg[g + 1] - gbeg[g];
+            if (!cnt) continue;
+            hipStream_t gs = gstream[g];
+            if (gs != st) HIPCHK(hipStreamWaitEvent(gs, c->ev_fork, 0));
+            const u32 *lst = d_slot + gbeg[g];
+            kd_huff<<<cnt, 128, 0, gs>>>(d_in, nbytes, d_cand + i0, block_size, S, d_bwt, d_meta, d_symmap, lst);
+            KCHECK();
+            kd_set_meta<<<(cnt + 63) / 64, 64, 0, gs>>>(lst, cnt, d_meta, block_size, d_n, d_orig);
+            KCHECK();
+            // MTF positions -> BWT bytes, in place
+            const dim3 gm((block_size + 4 * KD_MCHUNK - 1) / (4 * KD_MCHUNK), cnt);
+            kd_imtf_perm<<<gm, 256, 0, gs>>>(d_bwt, lst, d_n, S, CH, d_perm);
+            KCHECK();
+            kd_imtf_compose<<<cnt, 64, 0, gs>>>(lst, d_n, d_symmap, CH, d_perm);
+            KCHECK();
+            kd_imtf_apply<<<gm, 256, 0, gs>>>(d_bwt, lst, d_n, S, CH, d_perm);
+            KCHECK();
+            kd_hist<<<cnt, 256, 0, gs>>>(d_bwt, lst, d_n, S, d_base);
+            KCHECK();
+            kd_merge<<<dim3(KD_MPARTS, cnt), 64, 0, gs>>>(d_bwt, lst, d_n, S, d_base, d_merged);
+            KCHECK();
+            const dim3 gr((RS + 255) / 256, cnt);
+            kd_walk_a<<<gr, 256, 0, gs>>>(d_merged, d_n, d_orig, S, RS, d_rinfo, lst);
+            KCHECK();
+            kd_walk_b<<<(cnt + 63) / 64, 64, 0, gs>>>(d_n, d_orig, RS, d_rinfo, d_visits, d_nvis, d_cyc, cnt, lst);
+            KCHECK();
+            kd_walk_c<<<gr, 256, 0, gs>>>(d_merged, d_n, d_orig, S, RS, d_rinfo, d_visits, d_nvis, d_cyc, d_tt, lst);
+            KCHECK();
+            kd_cycfill<<<dim3(64, cnt), 256, 0, gs>>>(d_n, d_cyc, S, d_tt, lst);
+            KCHECK();
+            kd_segs<<<dim3(KD_SEGS, cnt), 64, 0, gs>>>(d_tt, d_n, S, d_segstart, lst);
+            KCHECK();
+            kd_unrle_count<<<dim3(KD_SEGS, cnt), 64, 0, gs>>>(d_tt, d_n, S, d_segstart, d_segres, lst);
+            KCHECK();
+            kd_unrle_resolve<<<(cnt + 63) / 64, 64, 0, gs>>>(d_segres, d_segin, d_outlen, d_flags, cnt, lst);
+            KCHECK();
+        }
+        for (u32 g = 0; g < KD_GROUPS; g++)
+            if (gbeg[g + 1] > gbeg[g]) HIPCHK(hipStreamSynchronize(gstream[g]));
+        std::vector<u32> s_outlen(nbatch), s_flags(nbatch); // per candidate slot
         HIPCHK(hipMemcpyAsync(meta.data(), d_meta, (size_t)nbatch * KM_WORDS * sizeof(u32),
                               hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(s_outlen.data(), d_outlen, nbatch * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(s_flags.data(), d_flags, nbatch * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         // chain walk inside the batch, S/BZip2InputStream.swift:201-242
         std::vector<u32> chain; // batch slot of block k
@@ -1246,57 +1347,17 @@ int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size
         }
         const u32 nb = (u32)chain.size();
         if (nb) {
-            std::vector<u32> h_n(nb), h_orig(nb), h_crc(nb);
-            u32 maxn = 0;
+            std::vector<u32> h_crc(nb), h_outlen(nb), h_flags(nb);
             u32 first_bad_ptr = nb; // S/BZip2BlockDecompressor.swift:332-334
             for (u32 k = 0; k < nb; k++) {
                 const u32 *mt = &meta[(size_t)chain[k] * KM_WORDS];
-                h_n[k] = mt[KM_N];
-                h_orig[k] = mt[KM_ORIG];
                 h_crc[k] = mt[KM_CRC];
-                if (h_orig[k] >= h_n[k]) {
-                    if (first_bad_ptr == nb) first_bad_ptr = k;
-                    h_n[k] = 0;
-                    h_orig[k] = 0;
-                }
-                maxn = std::max(maxn, h_n[k]);
+                if (mt[KM_ORIG] >= mt[KM_N] && first_bad_ptr == nb) first_bad_ptr = k;
+                h_outlen[k] = s_outlen[chain[k]];
+                h_flags[k] = s_flags[chain[k]];
             }
-            HIPCHK(hipMemcpyAsync(d_slot, chain.data(), nb * 4, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(d_n, h_n.data(), nb * 4, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(d_orig, h_orig.data(), nb * 4, hipMemcpyHostToDevice, st));
-            if (maxn) {
-                // MTF positions -> BWT bytes, in place
-                const dim3 gm((maxn + 4 * KD_MCHUNK - 1) / (4 * KD_MCHUNK), nb);
-                kd_imtf_perm<<<gm, 256, 0, st>>>(d_bwt, d_slot, d_n, S, CH, d_perm);
-                KCHECK();
-                kd_imtf_compose<<<nb, 64, 0, st>>>(d_slot, d_n, d_symmap, CH, d_perm);
-                KCHECK();
-                kd_imtf_apply<<<gm, 256, 0, st>>>(d_bwt, d_slot, d_n, S, CH, d_perm);
-                KCHECK();
-                kd_hist<<<nb, 256, 0, st>>>(d_bwt, d_slot, d_n, S, d_base);
-                KCHECK();
-                kd_merge<<<dim3(KD_MPARTS, nb), 64, 0, st>>>(d_bwt, d_slot, d_n, S, d_base, d_merged);
-                KCHECK();
-                const dim3 gr((RS + 255) / 256, nb);
-                kd_walk_a<<<gr, 256, 0, st>>>(d_merged, d_n, d_orig, S, RS, d_rinfo);
-                KCHECK();
-                kd_walk_b<<<(nb + 63) / 64, 64, 0, st>>>(d_n, d_orig, RS, d_rinfo, d_visits, d_nvis, d_cyc, nb);
-                KCHECK();
-                kd_walk_c<<<gr, 256, 0, st>>>(d_merged, d_n, d_orig, S, RS, d_rinfo, d_visits, d_nvis, d_cyc, d_tt);
-                KCHECK();
-                kd_cycfill<<<dim3(64, nb), 256, 0, st>>>(d_n, d_cyc, S, d_tt);
-                KCHECK();
-            }
-            kd_segs<<<dim3(KD_SEGS, nb), 64, 0, st>>>(d_tt, d_n, S, d_segstart);
-            KCHECK();
-            kd_unrle_count<<<dim3(KD_SEGS, nb), 64, 0, st>>>(d_tt, d_n, S, d_segstart, d_segres);
-            KCHECK();
-            kd_unrle_resolve<<<(nb + 63) / 64, 64, 0, st>>>(d_segres, d_segin, d_outlen, d_flags, nb);
-            KCHECK();
-            std::vector<u32> h_outlen(nb), h_flags(nb);
-            HIPCHK(hipMemcpyAsync(h_outlen.data(), d_outlen, nb * 4, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipMemcpyAsync(h_flags.data(), d_flags, nb * 4, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
+            // the chain in output order, for the stage that writes (kd_unrle_write)
+            HIPCHK(hipMemcpyAsync(d_order, chain.data(), nb * 4, hipMemcpyHostToDevice, st));
             // blocks the reference would have handed out: up to the first one it fails on, and that
             // fit (in block order: start pointer, then room for the block's bytes, then its last run).
             // The reference stops at the first block whose CRC fails, so a damaged block that decodes
@@ -1329,9 +1390,8 @@ int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size
                 if (good) {
                     u8 *o = d_out + out_total;
                     HIPCHK(hipMemcpyAsync(d_outbase, h_base.data(), (good + 1) * 4, hipMemcpyHostToDevice, st));
-                    kd_unrle_write<<<dim3(KD_SEGS, good), 64, 0, st>>>(
-                        d_tt + (size_t)k0 * S, d_n + k0, S, d_segstart + (size_t)k0 * (KD_SEGS + 1),
-                        d_segin + (size_t)k0 * KD_SEGS * 2, d_outbase, o);
+                    kd_unrle_write<<<dim3(KD_SEGS, good), 64, 0, st>>>(d_tt, d_n, S, d_segstart, d_segin, d_outbase, o,
+                                                                       d_order + k0);
                     KCHECK();
                     const u32 ETPB = (maxlen + 4095) / 4096 + 1;
                     if (ETPB > ETPB_MAX) throw HipError(BZ2HIP_E_HIP, "internal: decoded block longer than 52 x block size");
