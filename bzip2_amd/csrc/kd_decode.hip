@@ -329,6 +329,10 @@ __global__ __launch_bounds__(128) void kd_huff(const u8 *__restrict__ in, u64 nb
     }
     __syncthreads();
     const u32 status0 = s_status;
+    // The two serial loops below set the decoder's time, and waves of the later stages of other blocks
+    // (the other stream) now share their SIMDs: highest wave priority (measured: the long group's
+    // Huffman stage 85.1 -> 82.1 ms, what it takes with the chip to itself).
+    __builtin_amdgcn_s_setprio(3);
     if (status0 == KS_OK) {
         const int eob = __builtin_amdgcn_readfirstlane((int)s_eob);
         if (wv == 0) {
@@ -778,28 +782,20 @@ __global__ __launch_bounds__(256) void kd_imtf_apply(u8 *__restrict__ bwt, const
 #define KD_MPARTS 8 // the counting sort of a block runs as 8 waves over 8 index ranges
 __device__ __forceinline__ u32 kd_part_len(u32 n) { return (((n + KD_MPARTS - 1) / KD_MPARTS) + 255u) & ~255u; }
 
-// base[part][v] = first merged slot of byte v for the indices of that part
+// cnt[part][v] = number of bytes v among the indices of that part (one workgroup per part)
 __global__ __launch_bounds__(256) void kd_hist(const u8 *__restrict__ bwt, const u32 *__restrict__ slot,
                                                const u32 *__restrict__ nArr, u32 S,
-                                               u32 *__restrict__ base) {
-    const u32 b = slot[blockIdx.x];
-    __shared__ u32 h[KD_MPARTS][256];
-    __shared__ u32 sm[8];
-    for (int q = 0; q < KD_MPARTS; q++) h[q][threadIdx.x] = 0;
+                                               u32 *__restrict__ cntArr) {
+    const u32 b = slot[blockIdx.y], part = blockIdx.x;
+    __shared__ u32 h[256];
+    h[threadIdx.x] = 0;
     __syncthreads();
     const u8 *p = bwt + (size_t)b * S;
-    const u32 n = nArr[b];
-    const u32 pl = kd_part_len(n);
-    for (u32 i = threadIdx.x; i < n; i += 256) atomicAdd(&h[i / pl][p[i]], 1u);
+    const u32 nn = nArr[b], pl = kd_part_len(nn);
+    const u32 n = min(nn, (part + 1u) * pl);
+    for (u32 i = part * pl + threadIdx.x; i < n; i += 256) atomicAdd(&h[p[i]], 1u);
     __syncthreads();
-    u32 c[KD_MPARTS], sum = 0;
-    for (int q = 0; q < KD_MPARTS; q++) { c[q] = h[q][threadIdx.x]; sum += c[q]; }
-    u32 tot;
-    u32 ex = block_excl_scan_add<256>(sum, sm, &tot);
-    for (int q = 0; q < KD_MPARTS; q++) {
-        base[((size_t)b * KD_MPARTS + q) * 256 + threadIdx.x] = ex;
-        ex += c[q];
-    }
+    cntArr[((size_t)b * KD_MPARTS + part) * 256 + threadIdx.x] = h[threadIdx.x];
 }
 
 // merged[base[v]++] = (i << 8) + v in index order (S/BZip2BlockDecompressor.swift:346-350); one wave
@@ -810,7 +806,29 @@ __global__ __launch_bounds__(64) void kd_merge(const u8 *__restrict__ bwt, const
     const u32 b = slot[blockIdx.y], part = blockIdx.x;
     const int lane = lane_id();
     __shared__ u32 run[256];
-    for (int q = lane; q < 256; q += 64) run[q] = base[((size_t)b * KD_MPARTS + part) * 256 + q];
+    {
+        // first merged slot of byte v for this part = bytes below v in the whole block + bytes v in
+        // the parts before this one (lane holds v = 4 lane .. 4 lane + 3)
+        const uint4 *cp = (const uint4 *)(base + (size_t)b * KD_MPARTS * 256) + lane;
+        u32 tot[4] = {0, 0, 0, 0}, before[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (u32 q = 0; q < KD_MPARTS; q++) {
+            const uint4 c4 = cp[q * 64];
+            const u32 cc[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                tot[j] += cc[j];
+                if (q < part) before[j] += cc[j];
+            }
+        }
+        const u32 mine = tot[0] + tot[1] + tot[2] + tot[3];
+        u32 ex = wave_incl_scan_add(mine) - mine;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            run[lane * 4 + j] = ex + before[j];
+            ex += tot[j];
+        }
+    }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
     const u8 *p = bwt + (size_t)b * S;
@@ -952,7 +970,7 @@ __device__ __forceinline__ u32 kd_fcompose(u32 a, u32 b) { // a earlier, b later
     return ((b >> (a & 1u)) & 1u) | (((b >> ((a >> 1) & 1u)) & 1u) << 1);
 }
 
-#define KD_SEGS 16 // a block's bytes are cut at run heads into up to 16 pieces, one wave each
+#define KD_SEGS 64 // a block's bytes are cut at run heads into up to 64 pieces, one wave each
 
 // One piece [a, e) of a block (a is a run head, e a run head or n), entered in state s_in with the
 // output offset off: returns the state after it and advances off; WRITE stores the bytes.
@@ -1305,7 +1323,7 @@ int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size
             KCHECK();
             kd_imtf_apply<<<gm, 256, 0, gs>>>(d_bwt, lst, d_n, S, CH, d_perm);
             KCHECK();
-            kd_hist<<<cnt, 256, 0, gs>>>(d_bwt, lst, d_n, S, d_base);
+            kd_hist<<<dim3(KD_MPARTS, cnt), 256, 0, gs>>>(d_bwt, lst, d_n, S, d_base);
             KCHECK();
             kd_merge<<<dim3(KD_MPARTS, cnt), 64, 0, gs>>>(d_bwt, lst, d_n, S, d_base, d_merged);
             KCHECK();
