@@ -1293,8 +1293,9 @@ static void stream_job(bz2hip_ctx *c, const bz2hip_ctx::StreamWorker::Job &job) 
     const size_t n = W.carry + job.n;
     const size_t bound = bz2hip_compress_bound(n) + 16;
     if (W.d_in_cap < n) {
-        // grow the device input buffer, keeping the carried bytes
-        const size_t want = n + (n >> 2) + ((size_t)c->s_level * 200000u);
+        // the device input buffer: sized for the largest hand-over plus a carried block; grown
+        // (keeping the carried bytes) only if a block of long runs carries more than that
+        const size_t want = std::max(n + (n >> 2), W.pin_cap + (size_t)c->s_level * 400000u);
         u8 *nin = nullptr;
         HIPCHK(hipMalloc((void **)&nin, want + 64));
         if (W.carry) HIPCHK(hipMemcpy(nin, W.d_in, W.carry, hipMemcpyDeviceToDevice));
@@ -1332,6 +1333,12 @@ static void stream_job(bz2hip_ctx *c, const bz2hip_ctx::StreamWorker::Job &job) 
             W.pin_out_cap = c->h_out_cap + 64;
         }
         u8 *tmp = W.pin_out;
+        if (c->s_out.capacity() < tlen) {
+            // the output queue grows once to the size of a job's output instead of doubling its way
+            // there (each doubling is a copy and a fresh set of page faults)
+            std::lock_guard<std::mutex> lk(W.mu);
+            c->s_out.reserve(c->s_out.size() + c->h_out_cap / 2);
+        }
         if (tlen) HIPCHK(hipMemcpy(tmp, c->h_out, tlen, hipMemcpyDeviceToHost));
         if (c->s_bitcnt > 0 && tlen) tmp[0] |= (u8)c->s_bitbuf;
         const size_t full = job.final ? tlen : (size_t)(bitpos / 8);
