@@ -1476,7 +1476,10 @@ static int stream_write_async(bz2hip_ctx *c, const uint8_t *p, size_t n) {
             std::lock_guard<std::mutex> lk(W.mu);
             go = W.active == 0;
         }
-        if (go) stream_submit(c, false);
+        if (go) {
+            stream_submit(c, false);
+            if (int rc = stream_error(c)) return rc; // the rest of the stream would be dropped anyway
+        }
     }
     return stream_error(c);
 }
