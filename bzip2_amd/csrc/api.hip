@@ -1333,11 +1333,11 @@ static void stream_job(bz2hip_ctx *c, const bz2hip_ctx::StreamWorker::Job &job) 
             W.pin_out_cap = c->h_out_cap + 64;
         }
         u8 *tmp = W.pin_out;
-        if (c->s_out.capacity() < tlen) {
+        {
             // the output queue grows once to the size of a job's output instead of doubling its way
             // there (each doubling is a copy and a fresh set of page faults)
             std::lock_guard<std::mutex> lk(W.mu);
-            c->s_out.reserve(c->s_out.size() + c->h_out_cap / 2);
+            if (c->s_out.capacity() < tlen) c->s_out.reserve(c->s_out.size() + c->h_out_cap / 2);
         }
         if (tlen) HIPCHK(hipMemcpy(tmp, c->h_out, tlen, hipMemcpyDeviceToHost));
         if (c->s_bitcnt > 0 && tlen) tmp[0] |= (u8)c->s_bitbuf;
