@@ -27,6 +27,21 @@ def main(argv=None):
     ctx = Context()
     rc = 0
 
+    def compress_stream(fin, fout):
+        """fin -> fout through the incremental API (the reference's BZip2OutputStream.write into a
+        sink): constant memory, and the library compresses while this thread reads and writes"""
+        ctx.stream_begin(level)
+        while True:
+            piece = fin.read(16 << 20)
+            if not piece:
+                break
+            ctx.stream_write(piece)
+            while ctx.stream_pending():
+                fout.write(ctx.stream_read(1 << 24))
+        ctx.stream_finish()
+        while ctx.stream_pending():
+            fout.write(ctx.stream_read(1 << 24))
+
     def decode(z):
         """every stream of z, concatenated -> (code, bytes)"""
         out = b""
@@ -50,6 +65,9 @@ def main(argv=None):
 
     try:
         if not a.files:
+            if not a.decompress:
+                compress_stream(sys.stdin.buffer, sys.stdout.buffer)
+                return rc
             data = sys.stdin.buffer.read()
             if a.decompress:
                 code, out = decode(data)
@@ -57,10 +75,23 @@ def main(argv=None):
                 if code:
                     print(f"bzip2_amd: (stdin): error {code}", file=sys.stderr)
                     rc = 2
-            else:
-                sys.stdout.buffer.write(ctx.compress(data, level))
             return rc
         for path in a.files:
+            if not a.decompress:
+                dst = path + ".bz2"
+                if a.stdout:
+                    with open(path, "rb") as f:
+                        compress_stream(f, sys.stdout.buffer)
+                    continue
+                if os.path.exists(dst) and not a.force:
+                    print(f"bzip2_amd: {dst} exists (use -f)", file=sys.stderr)
+                    rc = 1
+                    continue
+                with open(path, "rb") as f, open(dst, "wb") as g:
+                    compress_stream(f, g)
+                if not a.keep:
+                    os.remove(path)
+                continue
             with open(path, "rb") as f:
                 data = f.read()
             if a.decompress:
@@ -70,9 +101,6 @@ def main(argv=None):
                     rc = 2
                     continue
                 dst = path[:-4] if path.endswith(".bz2") else path + ".out"
-            else:
-                out = ctx.compress(data, level)
-                dst = path + ".bz2"
             if a.stdout:
                 sys.stdout.buffer.write(out)
                 continue
