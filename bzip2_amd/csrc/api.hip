@@ -1442,6 +1442,7 @@ static int stream_error(bz2hip_ctx *c) {
     return c->sw.err;
 }
 
+enum { STREAM_GO_SYNC = 1 }; // stream_write_async: nothing taken, use the synchronous path (not an error code)
 static int stream_write_async(bz2hip_ctx *c, const uint8_t *p, size_t n) {
     auto &W = c->sw;
     if (int rc = stream_error(c)) return rc;
@@ -1460,8 +1461,13 @@ static int stream_write_async(bz2hip_ctx *c, const uint8_t *p, size_t n) {
         W.pin_cap = 0;
         for (int k = 0; k < 2; k++)
             if (hipHostMalloc((void **)&W.pin[k], cap, hipHostMallocDefault) != hipSuccess) {
+                // no page-locked memory to be had: this stream compresses inside write / finish
+                // (nothing has been buffered yet: the buffers are sized before the first byte is taken)
                 (void)hipGetLastError();
-                return fail(c, BZ2HIP_E_NOMEM, "page-locked allocation failed");
+                if (W.pin[0]) (void)hipHostFree(W.pin[0]);
+                W.pin[0] = W.pin[1] = nullptr;
+                c->s_async = false;
+                return STREAM_GO_SYNC; // the caller goes on with the synchronous path
             }
         W.pin_cap = cap;
     }
@@ -1488,7 +1494,14 @@ extern "C" int bz2hip_stream_write(bz2hip_ctx *c, const uint8_t *p, size_t n) {
     if (!c) return BZ2HIP_E_PARAM;
     if (!c->s_open || c->s_finished) return fail(c, BZ2HIP_E_STATE, "Write beyond end of stream");
     if (n && !p) return fail(c, BZ2HIP_E_PARAM, "null pointer");
-    if (c->s_async) return stream_write_async(c, p, n);
+    if (c->s_async) {
+        try {
+            const int rc = stream_write_async(c, p, n);
+            if (rc != STREAM_GO_SYNC) return rc;
+        } catch (const std::exception &e) { // std::thread could not start
+            return fail(c, BZ2HIP_E_NOMEM, e.what());
+        }
+    }
     try {
         c->s_in.insert(c->s_in.end(), p, p + n);
     } catch (const std::bad_alloc &) {
@@ -1504,7 +1517,11 @@ extern "C" int bz2hip_stream_finish(bz2hip_ctx *c) {
     if (c->s_finished) return BZ2HIP_OK; // finish() is idempotent (S/BZip2OutputStream.swift:151)
     if (c->s_async) {
         if (int rc0 = stream_error(c)) return rc0;
-        stream_submit(c, true);
+        try {
+            stream_submit(c, true);
+        } catch (const std::exception &e) { // std::thread could not start
+            return fail(c, BZ2HIP_E_NOMEM, e.what());
+        }
         stream_drain(c);
         const int rc1 = stream_error(c);
         if (rc1 == BZ2HIP_OK) c->s_finished = true;
