@@ -1,5 +1,7 @@
+"""One compress_device of mixed256; with BZ2HIP_DEBUG=2 the library prints the S- and L-list sizes of every
+doubling round to stderr."""
 import os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from bzip2_amd import Context, corpus
 data = corpus.mixed(256, corpus.MIXED256_SEED)

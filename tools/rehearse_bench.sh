@@ -1,3 +1,5 @@
+#!/bin/bash
+# bench.py at N = 1, then a 2-rank rehearsal of --gpus 2 on one GPU (gloo, both ranks on cuda:0)
 set -e
 mkdir -p gpurun_out/r2
 timeout -k 10 300 python bench.py --steps 5 --warmup 2 > gpurun_out/r2/bench1.json 2> gpurun_out/r2/bench1.err
