@@ -7,7 +7,7 @@
 // Element word E (u64):  [59:40] grp = SA position of the element's group head
 //                        [39:20] k2  = rank((i + h) mod n), filled in per round
 //                        [19: 0] i   = rotation start
-// Round 0: the first d0 symbols of every rotation (dense symbol codes, bps bits each, d0*bps <= 40)
+// Round 0: the first d0 symbols of every rotation (dense symbol codes as one number in base alphabet size, < 2^40)
 //   are packed into bits [59:20]; 5 LSD radix passes of 8 bits over those 40 bits; ranks by head
 //   flags.  Sorted depth h = d0.
 // Round r: only rotations in groups of size > 1 are still listed.  Groups of <= GS elements that
@@ -50,6 +50,18 @@ enum { CLS_NONE = 0, CLS_SINGLE = 1, CLS_SMALL = 2, CLS_LKEEP = 3 };
 #define CROSS INT_MAX
 #define NOHEAD (INT_MIN / 2)
 
+// Round-0 depth: the key is the first d0 symbols as ONE number in base `uniq` (the block's alphabet
+// size), the largest d0 with uniq^d0 <= 2^r0bits: order-preserving like bit fields, but an alphabet
+// of 17..101 symbols (text) gets 6 symbols into 40 bits instead of 5, one of 5 gets 17 instead of 13.
+__device__ __forceinline__ u32 r0_depth(u32 uniq, u32 r0bits) {
+    if (uniq <= 2) return r0bits;
+    const u64 lim = 1ull << r0bits;
+    u64 p = uniq;
+    u32 d = 1;
+    while (p * uniq <= lim && d < 63) { p *= uniq; d++; } // (keys are < uniq^d0 <= 2^r0bits)
+    return d;
+}
+
 // ------------------------------------------------------------------ per-block control
 __global__ void k2_reset(const u32 *__restrict__ nArr, const u32 *__restrict__ present,
                          u32 *mS, u32 *mL, u32 *mSn, u32 *mLn, u32 *hcur, u32 *huse, u32 *state,
@@ -59,9 +71,7 @@ __global__ void k2_reset(const u32 *__restrict__ nArr, const u32 *__restrict__ p
     if (b >= nb) return;
     u32 uniq = 0;
     for (int q = 0; q < 8; q++) uniq += __popc(present[b * 8 + q]);
-    u32 bps = 1;
-    while ((1u << bps) < uniq) bps++;
-    u32 d0 = r0bits / bps;
+    u32 d0 = r0_depth(uniq, r0bits);
     mS[b] = 0; mL[b] = 0; mSn[b] = 0; mLn[b] = 0;
     hcur[b] = d0; huse[b] = d0;
     state[b] = nArr[b] > 0 ? ST_ACTIVE : ST_DONE;
@@ -132,7 +142,7 @@ __global__ __launch_bounds__(256) void k2_ctl(const u32 *__restrict__ nArr, u32 
 struct R0Tile {
     u8 smap[256];
     u8 t[RTILE + 64];
-    u32 bps;
+    u32 uniq;
 };
 __device__ __forceinline__ void r0_tile_load(R0Tile &L, const u8 *__restrict__ T,
                                              const u32 *__restrict__ present, u32 b, u32 S, u32 n,
@@ -144,12 +154,7 @@ __device__ __forceinline__ void r0_tile_load(R0Tile &L, const u8 *__restrict__ T
         for (u32 wi = 0; wi < (v >> 5); wi++) cnt += __popc(pw[wi]);
         cnt += __popc(pw[v >> 5] & ((1u << (v & 31)) - 1u));
         L.smap[v] = (u8)cnt;
-        if (v == 255) {
-            u32 uniq = cnt + ((pw[7] >> 31) & 1u);
-            u32 bps = 1;
-            while ((1u << bps) < uniq) bps++;
-            L.bps = bps;
-        }
+        if (v == 255) L.uniq = cnt + ((pw[7] >> 31) & 1u);
     }
     const u8 *t = T + (size_t)b * S;
     for (u32 q = threadIdx.x; q < RTILE + 64; q += RT_THREADS) {
@@ -161,8 +166,8 @@ __device__ __forceinline__ void r0_tile_load(R0Tile &L, const u8 *__restrict__ T
 }
 __device__ __forceinline__ u64 r0_key(const R0Tile &L, u32 local, u32 i, u32 d0) {
     u64 kk = 0;
-    const u32 bps = L.bps;
-    for (u32 q = 0; q < d0; q++) kk = (kk << bps) | L.smap[L.t[local + q]];
+    const u32 uniq = L.uniq;
+    for (u32 q = 0; q < d0; q++) kk = kk * uniq + L.smap[L.t[local + q]];
     return (kk << KEY_SHIFT) | (u64)i;
 }
 
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(RT_THREADS) void k2_radix_hist(const u64 *__restric
     if (FROM_T) {
         __shared__ R0Tile L;
         r0_tile_load(L, T, present, b, S, n, base);
-        const u32 d0 = r0bits / L.bps;
+        const u32 d0 = r0_depth(L.uniq, r0bits);
 #pragma unroll 4
         for (int k = 0; k < RT_ITEMS; k++) {
             const u32 local = k * RT_THREADS + threadIdx.x;
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(RT_THREADS, 4) void k2_radix_scatter(
     u32 d0 = 0;
     if (FROM_T) {
         r0_tile_load(L, T, present, b, S, n, base);
-        d0 = r0bits / L.bps;
+        d0 = r0_depth(L.uniq, r0bits);
     }
     __syncthreads();
     const u64 *kp = keyIn + (size_t)b * S;
