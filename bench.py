@@ -400,13 +400,14 @@ def main():
                                 "periodic_blocks": stats["periodic_blocks"]}
             res["stage_ms_per_step"] = {k: round(v["ms"] / prof_steps, 3) for k, v in prof.items() if v["launches"]}
         if world == 1:
-            # the decoder on the stream just written: informational, one pass
+            # the decoder on the stream just written: informational
             d_back = torch.empty(n_in + 64, dtype=torch.uint8, device=dev)
-            torch.cuda.synchronize()
-            td = time.perf_counter()
-            drc, dn = ctx.decompress_device(d_out.data_ptr(), out_len, d_back.data_ptr(), n_in)
-            torch.cuda.synchronize()
-            td = time.perf_counter() - td
+            for _ in range(2):  # the first pass allocates the decoder's workspace; the second is reported
+                torch.cuda.synchronize()
+                td = time.perf_counter()
+                drc, dn = ctx.decompress_device(d_out.data_ptr(), out_len, d_back.data_ptr(), n_in)
+                torch.cuda.synchronize()
+                td = time.perf_counter() - td
             res["decode"] = {"value": round(n_in / td / 1e6, 1), "unit": "MB/s", "ms": round(td * 1e3, 1),
                              "ok": bool(drc == 0 and dn == n_in and torch.equal(d_back[:dn], d_in))}
             del d_back
