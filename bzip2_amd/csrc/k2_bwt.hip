@@ -53,12 +53,21 @@ enum { CLS_NONE = 0, CLS_SINGLE = 1, CLS_SMALL = 2, CLS_LKEEP = 3 };
 // Round-0 depth: the key is the first d0 symbols as ONE number in base `uniq` (the block's alphabet
 // size), the largest d0 with uniq^d0 <= 2^r0bits: order-preserving like bit fields, but an alphabet
 // of 17..101 symbols (text) gets 6 symbols into 40 bits instead of 5, one of 5 gets 17 instead of 13.
-__device__ __forceinline__ u32 r0_depth(u32 uniq, u32 r0bits) {
+// What is left of the key space after d0 symbols takes a coarse, order-preserving bucket of the next
+// symbol: B = min(uniq, floor(2^r0bits / uniq^d0)) buckets, bucket(code) = code * scale >> 16 with
+// scale = (B << 16) / uniq (text, 55 symbols: d0 = 6 and 39 buckets of the seventh).  The depth that
+// the doubling counts on stays d0.  *xb = B | scale << 8 (B <= 255 here: uniq = 256 leaves B = 1).
+__device__ __forceinline__ u32 r0_depth(u32 uniq, u32 r0bits, u32 *xb = nullptr) {
+    if (xb) *xb = 1u;
     if (uniq <= 2) return r0bits;
     const u64 lim = 1ull << r0bits;
     u64 p = uniq;
     u32 d = 1;
     while (p * uniq <= lim && d < 63) { p *= uniq; d++; } // (keys are < uniq^d0 <= 2^r0bits)
+    if (xb) {
+        const u32 B = (u32)min((u64)min(uniq, 255u), lim / p);
+        *xb = B | (((B << 16) / uniq) << 8);
+    }
     return d;
 }
 
@@ -164,10 +173,12 @@ __device__ __forceinline__ void r0_tile_load(R0Tile &L, const u8 *__restrict__ T
     }
     __syncthreads();
 }
-__device__ __forceinline__ u64 r0_key(const R0Tile &L, u32 local, u32 i, u32 d0) {
+__device__ __forceinline__ u64 r0_key(const R0Tile &L, u32 local, u32 i, u32 d0, u32 xb) {
     u64 kk = 0;
     const u32 uniq = L.uniq;
     for (u32 q = 0; q < d0; q++) kk = kk * uniq + L.smap[L.t[local + q]];
+    const u32 B = xb & 255u;
+    if (B > 1u) kk = kk * B + (((u32)L.smap[L.t[local + d0]] * (xb >> 8)) >> 16);
     return (kk << KEY_SHIFT) | (u64)i;
 }
 
@@ -198,12 +209,13 @@ __global__ __launch_bounds__(RT_THREADS) void k2_radix_hist(const u64 *__restric
     if (FROM_T) {
         __shared__ R0Tile L;
         r0_tile_load(L, T, present, b, S, n, base);
-        const u32 d0 = r0_depth(L.uniq, r0bits);
+        u32 xb;
+        const u32 d0 = r0_depth(L.uniq, r0bits, &xb);
 #pragma unroll 4
         for (int k = 0; k < RT_ITEMS; k++) {
             const u32 local = k * RT_THREADS + threadIdx.x;
             if (base + local < n)
-                atomicAdd(&hist[(u32)(r0_key(L, local, base + local, d0) >> shift) & (RB - 1u)], 1u);
+                atomicAdd(&hist[(u32)(r0_key(L, local, base + local, d0, xb) >> shift) & (RB - 1u)], 1u);
         }
         __syncthreads();
         for (u32 q = threadIdx.x; q < RB; q += RT_THREADS) th[q] = hist[q];
@@ -317,10 +329,10 @@ __global__ __launch_bounds__(RT_THREADS, 4) void k2_radix_scatter(
     const int w = wave_id(), lane = lane_id();
     for (int q = threadIdx.x; q < 4 * (int)RB; q += RT_THREADS) (&whist[0][0])[q] = 0;
     __shared__ R0Tile L;
-    u32 d0 = 0;
+    u32 d0 = 0, xb = 1;
     if (FROM_T) {
         r0_tile_load(L, T, present, b, S, n, base);
-        d0 = r0_depth(L.uniq, r0bits);
+        d0 = r0_depth(L.uniq, r0bits, &xb);
     }
     __syncthreads();
     const u64 *kp = keyIn + (size_t)b * S;
@@ -333,7 +345,7 @@ __global__ __launch_bounds__(RT_THREADS, 4) void k2_radix_scatter(
     for (int k = 0; k < RT_ITEMS; k++) {
         const u32 i = base + w * (RTILE / 4) + k * 64 + lane;
         const u32 ic = i < n ? i : base; // base < n
-        keys[k] = FROM_T ? r0_key(L, ic - base, ic, d0) : kp[ic];
+        keys[k] = FROM_T ? r0_key(L, ic - base, ic, d0, xb) : kp[ic];
     }
     // Ranking, in two loops so that nothing waits inside them: the leaders' LDS atomics (with
     // return) of all 16 rows are issued back to back -- the LDS executes one wave's atomics in
