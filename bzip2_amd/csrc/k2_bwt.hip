@@ -954,6 +954,41 @@ __device__ __forceinline__ void bitonic_sort_lds(u64 *buf, int N) {
 #define RUNS_STRIDE (4 + 4 * NCAND * MAXRUNS)
 #define VSLOT(d) (((d) * 2654435761u) >> 19)
 
+// Votes of round 0: the sorted round-0 list (key << 20 | i, equal keys in index order) is sampled at
+// the first 64 slots of every fourth tile; neighbours with equal keys vote for their distance (one
+// atomic per stretch of equal distances).  The regions picked from these votes serve every round.
+__global__ __launch_bounds__(64) void k2_vote0(const u64 *__restrict__ sorted, const u32 *__restrict__ nArr,
+                                               const u32 *__restrict__ huse, u32 *__restrict__ pvote,
+                                               u32 S, u32 gtiles, u32 gnb) {
+    XCD_MAP(gtiles, gnb)
+    const u32 b = bz_b;
+    const u32 n = nArr[b];
+    const u32 t0 = bz_t * (4u * RTILE); // every fourth tile: the picks need counts, not a census
+    if (t0 + 1 >= n) return;
+    const int lane = lane_id();
+    const u64 *in = sorted + (size_t)b * S;
+    const u32 q = t0 + 1u + (u32)lane;
+    u32 vd = 0;
+    if (q < n) {
+        const u64 e = in[q], ep = in[q - 1];
+        if ((e >> KEY_SHIFT) == (ep >> KEY_SHIFT)) {
+            const u32 i1 = (u32)(e & E_IMASK), i0 = (u32)(ep & E_IMASK);
+            if (i1 > i0 && i1 - i0 > huse[b]) vd = i1 - i0;
+        }
+    }
+    const u32 vprev = __shfl_up(vd, 1, 64);
+    const bool vote = vd != 0;
+    const bool rh = vote && (lane == 0 || vprev != vd);
+    const u64 hm_ = __ballot(rh), vm_ = __ballot(vote);
+    if (rh) {
+        const u64 above = (lane == 63) ? 0ull : ((hm_ | ~vm_) & (~0ull << (lane + 1)));
+        const u32 cnt = (above ? (u32)__ffsll((unsigned long long)above) - 1u : 64u) - (u32)lane;
+        u32 *pv = pvote + ((size_t)b * VT + VSLOT(vd)) * 2;
+        atomicAdd(pv, cnt);
+        atomicMax(pv + 1, (cnt << 20) | vd);
+    }
+}
+
 __global__ __launch_bounds__(256) void k2_pick(const u32 *__restrict__ pvote,
                                                const u32 *__restrict__ nArr, u32 *__restrict__ cand,
                                                u32 *__restrict__ runs, u32 nb) {
@@ -1797,8 +1832,19 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
     else radix_sort5(c, nb, maxn, B.n, B.keyB, B.keyA, true);
     lrerank<MODE_ROUND0>(c, nb, maxn, B.n, ST_ACTIVE, B.keyB, B.keyA);
     bool first = true;
-    int rnd = 0; // doubling rounds launched so far
+    // Repeat distances are voted for on the round-0 list, so that the run rule already applies in the
+    // first doubling round (the rules are exact whatever the votes: a poor candidate costs time,
+    // never correctness).  Voting again after the first round, on ties twice as deep, changed no
+    // family's round count and cost 0.3 ms (measured), so the regions are listed once.
     HIPCHK(hipMemsetAsync(B.pvote, 0, (size_t)nb * VT * 2 * sizeof(u32), c->stream));
+    k2_vote0<<<xcd_grid((tiles + 3) / 4, nb), 64, 0, c->stream>>>(B.keyB, B.n, B.huse, B.pvote, B.S, (tiles + 3) / 4, (u32)nb);
+    KCHECK();
+    k2_pick<<<nb, 256, 0, c->stream>>>(B.pvote, B.n, B.cand, B.runs, nb);
+    KCHECK();
+    k2_viol<<<dim3(tiles, NCAND, nb), 256, 0, c->stream>>>(B.T, B.n, B.cand, B.vagg, B.S, B.TPB);
+    KCHECK();
+    k2_runs<<<cb, 256, 0, c->stream>>>(B.T, B.n, B.cand, B.vagg, B.runs, B.S, B.TPB, nb);
+    KCHECK();
     u32 finS = 0, finL = 0;
     bool anyfin = false;
     for (;;) {
@@ -1854,8 +1900,8 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
             ProfScope ps(c, P_BWT_SSORT);
             k2_ssort<MODE_NORMAL><<<xcd_grid((maxS + SC - 1) / SC, nb), RT_THREADS, 0, c->stream>>>(
                 B.slA, B.slB, B.slA, B.slB, B.par, B.mS, B.state, ST_ACTIVE, B.rank, B.T, B.bwt, B.n,
-                B.mSn, B.leftg, B.huse, rnd == 0 ? B.pvote : (u32 *)nullptr,
-                rnd == 0 ? (const u32 *)nullptr : B.runs, B.nheads, B.S, (maxS + SC - 1) / SC, nbarg(nb, 2));
+                B.mSn, B.leftg, B.huse, (u32 *)nullptr,
+                B.runs, B.nheads, B.S, (maxS + SC - 1) / SC, nbarg(nb, 2));
             KCHECK();
             KCHECK();
         }
@@ -1865,9 +1911,9 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
                 // long-repeat rules on the L-list (after k2_keys, before the sort)
                 ProfScope ps(c, P_BWT_KEYS);
                 const u32 lt = (maxL + RTILE - 1) / RTILE;
-                const u32 *runs = rnd == 0 ? (const u32 *)nullptr : B.runs;
+                const u32 *runs = B.runs;
                 k2_lap_p1<<<xcd_grid(lt, nb), RT_THREADS, 0, c->stream>>>(B.keyA, B.mL, B.state, B.huse, runs,
-                                                                         rnd == 0 ? B.pvote : (u32 *)nullptr, B.tileagg, B.S, B.TPB, lt, nbarg(nb, 4));
+                                                                         (u32 *)nullptr, B.tileagg, B.S, B.TPB, lt, nbarg(nb, 4));
                 KCHECK();
                 k2_lap_p2<<<nb, 256, (size_t)B.TPB * 8 * sizeof(u32), c->stream>>>(B.mL, B.state, B.tileagg,
                                                                                    B.r2agg, B.TPB);
@@ -1887,16 +1933,6 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
                 HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
             }
         }
-        if (rnd == 0) {
-            // the first round voted for repeat distances (S- and L-list): list their regions
-            k2_pick<<<nb, 256, 0, c->stream>>>(B.pvote, B.n, B.cand, B.runs, nb);
-            KCHECK();
-            k2_viol<<<dim3(tiles, NCAND, nb), 256, 0, c->stream>>>(B.T, B.n, B.cand, B.vagg, B.S, B.TPB);
-            KCHECK();
-            k2_runs<<<cb, 256, 0, c->stream>>>(B.T, B.n, B.cand, B.vagg, B.runs, B.S, B.TPB, nb);
-            KCHECK();
-        }
-        rnd++;
     }
     {
         // every finished rotation's BWT byte, in one streaming pass (before the tie flush, which
