@@ -1830,21 +1830,30 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
     // passes go (T) -> keyB -> keyA -> ... -> keyB, so the "input" of pass 0 is nominally keyA.
     if (r0p & 1) radix_sort5(c, nb, maxn, B.n, B.keyA, B.keyB, true);
     else radix_sort5(c, nb, maxn, B.n, B.keyB, B.keyA, true);
-    lrerank<MODE_ROUND0>(c, nb, maxn, B.n, ST_ACTIVE, B.keyB, B.keyA);
-    bool first = true;
     // Repeat distances are voted for on the round-0 list, so that the run rule already applies in the
     // first doubling round (the rules are exact whatever the votes: a poor candidate costs time,
     // never correctness).  Voting again after the first round, on ties twice as deep, changed no
-    // family's round count and cost 0.3 ms (measured), so the regions are listed once.
-    HIPCHK(hipMemsetAsync(B.pvote, 0, (size_t)nb * VT * 2 * sizeof(u32), c->stream));
-    k2_vote0<<<xcd_grid((tiles + 3) / 4, nb), 64, 0, c->stream>>>(B.keyB, B.n, B.huse, B.pvote, B.S, (tiles + 3) / 4, (u32)nb);
-    KCHECK();
-    k2_pick<<<nb, 256, 0, c->stream>>>(B.pvote, B.n, B.cand, B.runs, nb);
-    KCHECK();
-    k2_viol<<<dim3(tiles, NCAND, nb), 256, 0, c->stream>>>(B.T, B.n, B.cand, B.vagg, B.S, B.TPB);
-    KCHECK();
-    k2_runs<<<cb, 256, 0, c->stream>>>(B.T, B.n, B.cand, B.vagg, B.runs, B.S, B.TPB, nb);
-    KCHECK();
+    // family's round count and cost 0.3 ms (measured), so the regions are listed once.  The chain
+    // votes -> picks -> regions only reads the sorted list and T: it runs on the other stream beside
+    // the round-0 re-rank.
+    HIPCHK(hipEventRecord(c->ev_fork, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->stream_other, c->ev_fork, 0));
+    {
+        hipStream_t so = c->stream_other;
+        HIPCHK(hipMemsetAsync(B.pvote, 0, (size_t)nb * VT * 2 * sizeof(u32), so));
+        k2_vote0<<<xcd_grid((tiles + 3) / 4, nb), 64, 0, so>>>(B.keyB, B.n, B.huse, B.pvote, B.S, (tiles + 3) / 4, (u32)nb);
+        KCHECK();
+        k2_pick<<<nb, 256, 0, so>>>(B.pvote, B.n, B.cand, B.runs, nb);
+        KCHECK();
+        k2_viol<<<dim3(tiles, NCAND, nb), 256, 0, so>>>(B.T, B.n, B.cand, B.vagg, B.S, B.TPB);
+        KCHECK();
+        k2_runs<<<cb, 256, 0, so>>>(B.T, B.n, B.cand, B.vagg, B.runs, B.S, B.TPB, nb);
+        KCHECK();
+        HIPCHK(hipEventRecord(c->ev_join, so));
+    }
+    lrerank<MODE_ROUND0>(c, nb, maxn, B.n, ST_ACTIVE, B.keyB, B.keyA);
+    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    bool first = true;
     u32 finS = 0, finL = 0;
     bool anyfin = false;
     for (;;) {
