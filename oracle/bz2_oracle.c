@@ -107,20 +107,23 @@ size_t orc_rle1_block(const uint8_t *in, size_t n_in, int block_size, uint8_t *b
 }
 
 /* ------------------------------------------------------------------ BWT (tier 1) */
-static int g_tie_rule = 0;
-static int g_sa_block_size = 0; /* declared block size for tier 2's array length (0 = derive from n) */
-void orc_set_block_size(int block_size) { g_sa_block_size = block_size; }
-void orc_set_tie_rule(int rule) { g_tie_rule = rule; }
+/* No mutable configuration lives here: the declared block size (= level * 100000, the length of
+ * the reference's bwtBlock, S/BZip2BlockCompressor.swift:318) and the tie rule are ARGUMENTS of
+ * every function below, because the origin pointer of a periodic block depends on both. */
+int orc_declared_block_size(int n, int declared_block_size) {
+    /* 0 = the smallest declared size (multiple of 100000) that can hold n (n <= blockSize, :198-227) */
+    if (declared_block_size > 0) return declared_block_size;
+    return n <= 100000 ? 100000 : (n + 99999) / 100000 * 100000;
+}
 
 /* tier 2 (divsufsort_restate.c): the reference's own sorter, restated.  T[n] is written. */
 static int g_traps = 0;
 int orc_divsufsort_traps(void) { return g_traps; }
 
-void orc_bwt_divsufsort(uint8_t *T, int n, uint8_t *bwt, int *orig) {
-    /* the reference's array: blockSize + 1 ints, zeroed (S/BZip2BlockCompressor.swift:318);
-     * blockSize = the smallest declared size that can hold n (n <= blockSize, :198-227) */
-    int sa_len = (n <= 100000 ? 100000 : (n + 99999) / 100000 * 100000) + 1;
-    if (g_sa_block_size >= n && g_sa_block_size > 0) sa_len = g_sa_block_size + 1;
+void orc_bwt_divsufsort(uint8_t *T, int n, int declared_block_size, uint8_t *bwt, int *orig) {
+    /* the reference's array: blockSize + 1 ints, zeroed (S/BZip2BlockCompressor.swift:318) */
+    int sa_len = orc_declared_block_size(n, declared_block_size) + 1;
+    if (sa_len < n + 1) sa_len = n + 1; /* a caller that declares less than n: the reference would have refused the bytes */
     int *sa = (int *)calloc((size_t)sa_len, sizeof(int));
     int trap = 0;
     if (n > 0) T[n] = T[0]; /* S/BZip2BlockCompressor.swift:266 */
@@ -136,14 +139,15 @@ void orc_bwt_divsufsort(uint8_t *T, int n, uint8_t *bwt, int *orig) {
     free(sa);
 }
 
-void orc_bwt(const uint8_t *T, int n, uint8_t *bwt, int *orig, int *periodic) {
+void orc_bwt(const uint8_t *T, int n, int declared_block_size, int tie_rule, uint8_t *bwt, int *orig,
+             int *periodic) {
     if (periodic) *periodic = 1;
     *orig = 0;
     if (n == 0) return; /* S/BZip2DivSufSort.swift:3494-3495 */
-    if (g_tie_rule == 0) {
+    if (tie_rule == 0) {
         uint8_t *t2 = (uint8_t *)malloc((size_t)n + 1);
         memcpy(t2, T, (size_t)n);
-        orc_bwt_divsufsort(t2, n, bwt, orig);
+        orc_bwt_divsufsort(t2, n, declared_block_size, bwt, orig);
         free(t2);
         if (periodic) { /* k = n / (smallest period dividing n), via the KMP failure function */
             int *f = (int *)malloc(sizeof(int) * ((size_t)n + 1));
@@ -223,7 +227,7 @@ void orc_bwt(const uint8_t *T, int n, uint8_t *bwt, int *orig, int *periodic) {
     int o = rank[0];
     if (k > 1 && k < n) {
         /* tie rule for periodic blocks (DESIGN.md "orig on periodic blocks") */
-        if (g_tie_rule == 2) o += k - 1;
+        if (tie_rule == 2) o += k - 1;
     }
     if (k == n) o = 0; /* all-equal: S/BZip2DivSufSort.swift:3168-3174,3505 */
     *orig = o;
@@ -554,12 +558,12 @@ size_t orc_block_bound(int n) { return (size_t)n + (size_t)n / 2 + 40000; }
 
 /* S/BZip2BlockCompressor.swift:258-289 (after RLE1) */
 static void block_encode(bw_t *w, const uint8_t *block, int n, const uint8_t present[256],
-                         uint32_t crc) {
+                         uint32_t crc, int declared_block_size, int tie_rule) {
     uint8_t *bwt = (uint8_t *)malloc((size_t)n + 1);
     uint16_t *mtf = (uint16_t *)malloc(sizeof(uint16_t) * ((size_t)n + 2));
     uint8_t *selectors = (uint8_t *)malloc(ORC_MAX_SELECTORS + 8);
     int orig, per;
-    orc_bwt(block, n, bwt, &orig, &per);
+    orc_bwt(block, n, declared_block_size, tie_rule, bwt, &orig, &per);
     /* header :273-277 */
     bw_bits(w, 24, 0x314159);
     bw_bits(w, 24, 0x265359);
@@ -617,10 +621,10 @@ static void block_encode(bw_t *w, const uint8_t *block, int n, const uint8_t pre
 }
 
 uint64_t orc_block_compress(const uint8_t *rle_block, int n, const uint8_t present[256],
-                            uint32_t block_crc, uint8_t *bits) {
+                            uint32_t block_crc, int declared_block_size, int tie_rule, uint8_t *bits) {
     bw_t w;
     bw_init(&w, bits);
-    block_encode(&w, rle_block, n, present, block_crc);
+    block_encode(&w, rle_block, n, present, block_crc, declared_block_size, tie_rule);
     uint64_t total = w.total;
     bw_flush(&w);
     return total;
@@ -631,7 +635,7 @@ size_t orc_compress_bound(size_t n) { return n + n / 4 + 70000 + (n / 100000 + 1
 
 static int valid_level(int level) { return level >= 1 && level <= 9; }
 
-size_t orc_compress(const uint8_t *in, size_t n, int level, uint8_t *out, size_t cap,
+size_t orc_compress(const uint8_t *in, size_t n, int level, int tie_rule, uint8_t *out, size_t cap,
                     int *n_blocks) {
     if (!valid_level(level)) return 0; /* S/BZip2OutputStream.swift:173-175 */
     if (cap < orc_compress_bound(n)) return 0;
@@ -652,7 +656,7 @@ size_t orc_compress(const uint8_t *in, size_t n, int level, uint8_t *out, size_t
         uint32_t crc;
         pos += orc_rle1_block(in + pos, n - pos, bs, block, &blen, present, &crc);
         if (blen == 0) break; /* isEmpty :133-135 (cannot happen with pos < n) */
-        block_encode(&w, block, blen, present, crc);
+        block_encode(&w, block, blen, present, crc, bs, tie_rule);
         stream_crc = ((stream_crc << 1) | (stream_crc >> 31)) ^ crc; /* :139 */
         blocks++;
     }
@@ -688,6 +692,7 @@ typedef struct {
     const uint8_t *in;
     size_t n;
     int bs;
+    int tie_rule;
     const uint64_t *starts;
     int n_blocks;
     int next;
@@ -712,14 +717,14 @@ static void *mt_worker(void *arg) {
         uint32_t crc;
         orc_rle1_block(J->in + s, e - s, J->bs, block, &blen, present, &crc);
         J->bits[b] = (uint8_t *)calloc(1, orc_block_bound(blen));
-        J->nbits[b] = orc_block_compress(block, blen, present, crc, J->bits[b]);
+        J->nbits[b] = orc_block_compress(block, blen, present, crc, J->bs, J->tie_rule, J->bits[b]);
         J->crcs[b] = crc;
     }
     free(block);
     return NULL;
 }
 
-size_t orc_compress_mt(const uint8_t *in, size_t n, int level, uint8_t *out, size_t cap,
+size_t orc_compress_mt(const uint8_t *in, size_t n, int level, int tie_rule, uint8_t *out, size_t cap,
                        int threads, int *n_blocks) {
     if (!valid_level(level)) return 0;
     if (cap < orc_compress_bound(n)) return 0;
@@ -727,8 +732,8 @@ size_t orc_compress_mt(const uint8_t *in, size_t n, int level, uint8_t *out, siz
     uint64_t *starts = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)max_blocks);
     int nb = orc_split(in, n, level, starts, max_blocks);
     mt_job_t J;
-    g_sa_block_size = level * 100000; /* sizes tier 2's work array like the reference's bwtBlock */
-    J.in = in; J.n = n; J.bs = level * 100000; J.starts = starts; J.n_blocks = nb; J.next = 0;
+    J.in = in; J.n = n; J.bs = level * 100000; /* also sizes tier 2's work array, like the reference's bwtBlock */
+    J.tie_rule = tie_rule; J.starts = starts; J.n_blocks = nb; J.next = 0;
     pthread_mutex_init(&J.mu, NULL);
     J.bits = (uint8_t **)calloc((size_t)nb + 1, sizeof(uint8_t *));
     J.nbits = (uint64_t *)calloc((size_t)nb + 1, sizeof(uint64_t));

@@ -42,21 +42,25 @@ size_t orc_rle1_block(const uint8_t *in, size_t n_in, int block_size, uint8_t *b
 /* S/BZip2DivSufSort.swift:3487-3506 contract: last column of sorted cyclic rotations and
  * the sorted position of rotation 0.  *periodic is set to the period count k (block == w^k;
  * 1 if aperiodic).  The k rotations equal to rotation 0 are indistinguishable, so the origin
- * pointer of a periodic block depends on the sorter; orc_set_tie_rule selects it:
- *   0 (default)  tier 2: the reference's own sorter restated (divsufsort_restate.c)
- *   1            tier 1: prefix doubling, first position of the class
- *   2            tier 1: prefix doubling, last position of the class
+ * pointer of a periodic block depends on the sorter; tie_rule selects it:
+ *   0  tier 2: the reference's own sorter restated (divsufsort_restate.c)
+ *   1  tier 1: prefix doubling, first position of the class
+ *   2  tier 1: prefix doubling, last position of the class
  * Tier 1 is an independent algorithm kept as a cross-check: same bytes always, same origin
- * pointer on every aperiodic block. */
-void orc_bwt(const uint8_t *T, int n, uint8_t *bwt, int *orig, int *periodic);
+ * pointer on every aperiodic block.
+ * declared_block_size = the size the reference's caller declared (level * 100000,
+ * S/BZip2OutputStream.swift:177): it is the length of the zero-filled int array the sorter works
+ * in (S/BZip2BlockCompressor.swift:318), and tier 2's pointer on a periodic block can depend on it
+ * (one read lands in that zero tail, S/BZip2DivSufSort.swift:2589-2592).  0 = the smallest
+ * multiple of 100000 that holds n.  Both are arguments, never process state. */
+void orc_bwt(const uint8_t *T, int n, int declared_block_size, int tie_rule, uint8_t *bwt, int *orig,
+             int *periodic);
+int orc_declared_block_size(int n, int declared_block_size);
 
 /* Tier 2: restatement of the reference's BZip2DivSufSort (divsufsort_restate.c).  T must have
- * room for n + 1 bytes (T[n] := T[0]).  It is what orc_bwt uses under the default tie rule 0. */
-void orc_bwt_divsufsort(uint8_t *T, int n, uint8_t *bwt, int *orig);
+ * room for n + 1 bytes (T[n] := T[0]).  It is what orc_bwt uses under tie rule 0. */
+void orc_bwt_divsufsort(uint8_t *T, int n, int declared_block_size, uint8_t *bwt, int *orig);
 int orc_divsufsort_bwt(const uint8_t *T, int *sa_out, int n, int sa_len, int *trap);
-/* Declared block size (level * 100000) that sizes tier 2's zero-filled work array, as the
- * reference's bwtBlock is sized (0 = smallest multiple of 100000 that holds n). */
-void orc_set_block_size(int block_size);
 /* Number of blocks so far on which the reference would have failed with an index error. */
 int orc_divsufsort_traps(void);
 /* Brute-force cross-check (n small): sorts rotations with memcmp on the doubled string. */
@@ -88,25 +92,22 @@ void orc_huffman_codes(int n_tables, int alpha, int32_t lengths[ORC_MAX_TABLES][
  * S/BZip2BlockCompressor.swift:258-289.  Returns number of bits written.  `bits` must be
  * zeroed by the caller and hold at least n*5/4+2048 bytes... use orc_block_bound(n). */
 uint64_t orc_block_compress(const uint8_t *rle_block, int n, const uint8_t present[256],
-                            uint32_t block_crc, uint8_t *bits);
+                            uint32_t block_crc, int declared_block_size, int tie_rule, uint8_t *bits);
 size_t orc_block_bound(int n);
 
 /* Whole stream: S/BZip2OutputStream.swift:85-104,131-161,171-189.  Returns bytes written,
  * or 0 if cap is too small / level invalid.  n_blocks (optional) receives the block count. */
-size_t orc_compress(const uint8_t *in, size_t n, int level, uint8_t *out, size_t cap,
+size_t orc_compress(const uint8_t *in, size_t n, int level, int tie_rule, uint8_t *out, size_t cap,
                     int *n_blocks);
 size_t orc_compress_bound(size_t n);
 
 /* Same, but block-parallel over `threads` host threads (CPU baseline, all cores). */
-size_t orc_compress_mt(const uint8_t *in, size_t n, int level, uint8_t *out, size_t cap,
+size_t orc_compress_mt(const uint8_t *in, size_t n, int level, int tie_rule, uint8_t *out, size_t cap,
                        int threads, int *n_blocks);
 
 /* Block boundaries only: fills starts[0..max) with input offsets where blocks begin,
  * returns the number of blocks. */
 int orc_split(const uint8_t *in, size_t n, int level, uint64_t *starts, int max);
-
-/* Selects the tie rule for periodic blocks (see orc_bwt). */
-void orc_set_tie_rule(int rule);
 
 #ifdef __cplusplus
 }

@@ -42,9 +42,14 @@ def lib():
         L.orc_rle1_block.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p,
                                      C.POINTER(C.c_int), C.c_void_p, C.POINTER(C.c_uint32)]
         L.orc_bwt.restype = None
-        L.orc_bwt.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_bwt.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int),
+                              C.POINTER(C.c_int)]
         L.orc_bwt_divsufsort.restype = None
-        L.orc_bwt_divsufsort.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+        L.orc_bwt_divsufsort.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+        L.orc_divsufsort_bwt.restype = C.c_int
+        L.orc_divsufsort_bwt.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
+        L.orc_declared_block_size.restype = C.c_int
+        L.orc_declared_block_size.argtypes = [C.c_int, C.c_int]
         L.orc_bwt_bruteforce.restype = None
         L.orc_bwt_bruteforce.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int),
                                          C.POINTER(C.c_int)]
@@ -61,25 +66,22 @@ def lib():
         L.orc_huffman_codes.restype = None
         L.orc_huffman_codes.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_block_compress.restype = C.c_uint64
-        L.orc_block_compress.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_block_compress.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_int,
+                                         C.c_void_p]
         L.orc_block_bound.restype = C.c_size_t
         L.orc_block_bound.argtypes = [C.c_int]
         L.orc_compress.restype = C.c_size_t
-        L.orc_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t,
+        L.orc_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
                                    C.POINTER(C.c_int)]
         L.orc_compress_mt.restype = C.c_size_t
-        L.orc_compress_mt.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t,
+        L.orc_compress_mt.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
                                       C.c_int, C.POINTER(C.c_int)]
         L.orc_compress_bound.restype = C.c_size_t
         L.orc_compress_bound.argtypes = [C.c_size_t]
         L.orc_split.restype = C.c_int
         L.orc_split.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_int]
-        L.orc_set_block_size.restype = None
-        L.orc_set_block_size.argtypes = [C.c_int]
         L.orc_divsufsort_traps.restype = C.c_int
         L.orc_divsufsort_traps.argtypes = []
-        L.orc_set_tie_rule.restype = None
-        L.orc_set_tie_rule.argtypes = [C.c_int]
         L.orc_decompress.restype = C.c_int
         L.orc_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                      C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
@@ -127,25 +129,41 @@ def rle1_block(data, block_size):
     return consumed, block[: blen.value].copy(), present, crc.value
 
 
-def bwt(block):
-    """-> (bwt bytes, orig, period count k)"""
+def bwt(block, declared_block_size=0, tie_rule=0):
+    """-> (bwt bytes, orig, period count k).  declared_block_size = level * 100000 of the stream the
+    block belongs to (0 = the smallest multiple of 100000 that holds it); tie_rule 0 = the
+    reference's sorter (tier 2), 1 / 2 = first / last position of the class (tier 1)."""
     a = _u8(block)
     out = np.zeros(max(a.size, 1), dtype=np.uint8)
     orig = C.c_int(0)
     per = C.c_int(0)
-    lib().orc_bwt(_ptr(a), a.size, _ptr(out), C.byref(orig), C.byref(per))
+    lib().orc_bwt(_ptr(a), a.size, declared_block_size, tie_rule, _ptr(out), C.byref(orig), C.byref(per))
     return out[: a.size], orig.value, per.value
 
 
-def bwt_divsufsort(block):
+def bwt_divsufsort(block, declared_block_size=0):
     """Tier 2 (restated reference sorter) -> (bwt bytes, orig)"""
     a = _u8(block)
     t = np.zeros(a.size + 1, dtype=np.uint8)
     t[: a.size] = a
     out = np.zeros(max(a.size, 1), dtype=np.uint8)
     orig = C.c_int(0)
-    lib().orc_bwt_divsufsort(_ptr(t), a.size, _ptr(out), C.byref(orig))
+    lib().orc_bwt_divsufsort(_ptr(t), a.size, declared_block_size, _ptr(out), C.byref(orig))
     return out[: a.size], orig.value
+
+
+def divsufsort_raw(block, sa_len):
+    """Tier 2 on an int array of exactly sa_len entries -> (orig, trap).  trap = the reference
+    would have indexed past its array (S/BZip2DivSufSort.swift:2589-2592) on this block."""
+    a = _u8(block)
+    t = np.zeros(a.size + 1, dtype=np.uint8)
+    t[: a.size] = a
+    if a.size:
+        t[a.size] = a[0]
+    sa = np.zeros(max(sa_len, a.size + 1), dtype=np.int32)
+    trap = C.c_int(0)
+    o = lib().orc_divsufsort_bwt(_ptr(t), _ptr(sa), a.size, sa_len, C.byref(trap))
+    return o, trap.value
 
 
 def bwt_bruteforce(block):
@@ -203,24 +221,25 @@ def huffman_codes(n_tables, alpha, lengths):
     return merged
 
 
-def block_compress(rle_block, present, crc):
+def block_compress(rle_block, present, crc, declared_block_size=0, tie_rule=0):
     """-> (bytes holding the bits, nbits)"""
     a = _u8(rle_block)
     p = _u8(present)
     out = np.zeros(lib().orc_block_bound(a.size), dtype=np.uint8)
-    nbits = lib().orc_block_compress(_ptr(a), a.size, _ptr(p), crc, _ptr(out))
+    nbits = lib().orc_block_compress(_ptr(a), a.size, _ptr(p), crc, declared_block_size, tie_rule, _ptr(out))
     return out[: (nbits + 7) // 8].copy(), nbits
 
 
-def compress(data, level=9, threads=1):
+def compress(data, level=9, threads=1, tie_rule=0):
+    """Whole stream; every block is sorted in an array of level * 100000 + 1 ints whatever `threads`."""
     a = _u8(data)
     cap = lib().orc_compress_bound(a.size)
     out = np.zeros(cap, dtype=np.uint8)
     nb = C.c_int(0)
     if threads <= 1:
-        n = lib().orc_compress(_ptr(a), a.size, level, _ptr(out), cap, C.byref(nb))
+        n = lib().orc_compress(_ptr(a), a.size, level, tie_rule, _ptr(out), cap, C.byref(nb))
     else:
-        n = lib().orc_compress_mt(_ptr(a), a.size, level, _ptr(out), cap, threads, C.byref(nb))
+        n = lib().orc_compress_mt(_ptr(a), a.size, level, tie_rule, _ptr(out), cap, threads, C.byref(nb))
     if n == 0:
         raise ValueError("oracle compress failed (bad level or capacity)")
     return out[:n].tobytes(), nb.value
@@ -234,18 +253,9 @@ def split(data, level=9):
     return starts[:nb].copy()
 
 
-def set_block_size(block_size):
-    """Declared block size (level * 100000) sizing tier 2's work array; 0 = derive from n."""
-    lib().orc_set_block_size(block_size)
-
-
 def divsufsort_traps():
     """Blocks so far on which the reference's sorter would have indexed past its array."""
     return lib().orc_divsufsort_traps()
-
-
-def set_tie_rule(rule):
-    lib().orc_set_tie_rule(rule)
 
 
 # ---- decoder restatement (bz2_decode_oracle.c)

@@ -39,11 +39,11 @@ for k, d in cases.items():
         pos += used
         blocks.append(blk); presents.append(pres); crcs.append(crc); names.append(k)
 t = time.time()
-res = ctx.bwt(blocks)
+res = ctx.bwt(blocks, 900000)
 print("bwt time", time.time() - t, flush=True)
 obw = []
 for nm, blk, (bw, orig, rounds) in zip(names, blocks, res):
-    ob, oo, per = orc.bwt(blk)
+    ob, oo, per = orc.bwt(blk, 900000)
     obw.append(ob)
     check(f"bwt {nm} n={len(blk)} rounds={rounds} per={per}", np.array_equal(ob, bw) and oo == orig)
 res = ctx.mtf_rle2(obw, presents)
@@ -56,9 +56,9 @@ res = ctx.huffman([x[0] for x in om], [x[1] for x in om], [x[2] for x in om])
 for nm, (m, a, f), (nt, lens, sel) in zip(names, om, res):
     ont, ol, osel = orc.huffman_optimise(m, a, f)
     check(f"huff {nm} nt={nt}", nt == ont and np.array_equal(ol[:nt, :a], lens[:nt, :a]) and np.array_equal(osel, sel))
-res = ctx.block_compress(blocks, presents, crcs)
+res = ctx.block_compress(blocks, presents, crcs, 900000)
 for nm, blk, pres, crc, (bits, nbits) in zip(names, blocks, presents, crcs, res):
-    ob, on = orc.block_compress(blk, pres, crc)
+    ob, on = orc.block_compress(blk, pres, crc, 900000)
     check(f"block {nm} nbits={nbits}", on == nbits and np.array_equal(ob, bits))
 for k, d in cases.items():
     for lvl in (1, 9):

@@ -41,7 +41,7 @@ def test_stitch_host_only(orc):
     while pos < data.size:
         used, blk, pres, crc = orc.rle1_block(data[pos:], 100000)
         pos += used
-        bits, nbits = orc.block_compress(blk, pres, crc)
+        bits, nbits = orc.block_compress(blk, pres, crc, 100000)
         segs.append((bits, nbits, np.array([crc], dtype=np.uint32)))
     assert _lib.stitch(1, segs) == orc.compress(data, 1)[0]
     assert _lib.stitch(9, []) == bytes.fromhex("425a683917724538509000000000")

@@ -50,9 +50,9 @@ def _blocks(orc, cases, bs=900000):
 
 def test_stage_bwt(ctx, orc):
     names, blocks, _, _ = _blocks(orc, _cases())
-    res = ctx.bwt(blocks)
+    res = ctx.bwt(blocks, 900000)
     for nm, blk, (bw, orig, rounds) in zip(names, blocks, res):
-        ob, oo, per = orc.bwt(blk)
+        ob, oo, per = orc.bwt(blk, 900000)
         assert np.array_equal(ob, bw), nm
         assert oo == orig, (nm, per)
 
@@ -80,9 +80,9 @@ def test_stage_huffman(ctx, orc):
 
 def test_stage_block_compress(ctx, orc):
     names, blocks, presents, crcs = _blocks(orc, _cases())
-    res = ctx.block_compress(blocks, presents, crcs)
+    res = ctx.block_compress(blocks, presents, crcs, 900000)
     for nm, blk, pres, crc, (bits, nbits) in zip(names, blocks, presents, crcs, res):
-        ob, on = orc.block_compress(blk, pres, crc)
+        ob, on = orc.block_compress(blk, pres, crc, 900000)
         assert on == nbits and np.array_equal(ob, bits), nm
 
 
@@ -197,19 +197,15 @@ def test_periodic_blocks_fast_rules(orc):
     """BZ2HIP_TIE_FIRST / _LAST skip the replay; streams equal the oracle's tier 1 under the
     same rule and still decode."""
     from bzip2_amd import Context
-    try:
-        for rule in (1, 2):
-            orc.set_tie_rule(rule)
-            c = Context(tie_rule=rule)
-            for name in ("ab", "w31", "zeros_2M"):
-                d = _periodic_inputs()[name]
-                want, _ = orc.compress(d, 9)
-                got = c.compress(d, 9)
-                assert got == want, (name, rule)
-                assert bz2.decompress(got) == d.tobytes()
-            c.close()
-    finally:
-        orc.set_tie_rule(0)
+    for rule in (1, 2):
+        c = Context(tie_rule=rule)
+        for name in ("ab", "w31", "zeros_2M"):
+            d = _periodic_inputs()[name]
+            want, _ = orc.compress(d, 9, tie_rule=rule)
+            got = c.compress(d, 9)
+            assert got == want, (name, rule)
+            assert bz2.decompress(got) == d.tobytes()
+        c.close()
 
 
 def test_text900k_config2(ctx, orc):
@@ -572,15 +568,11 @@ def test_stage_entry_points_take_the_declared_block_size(ctx, orc):
     rng = np.random.default_rng(21)
     blocks = [np.tile(np.array([1, 0, 2], dtype=np.uint8), 900), np.tile(rng.integers(0, 4, 31, dtype=np.uint8), 3200),
               np.tile(np.frombuffer(b"ab", dtype=np.uint8), 40000), rng.integers(0, 256, 5000, dtype=np.uint8)]
-    try:
-        for declared in (100000, 400000, 900000):
-            orc.set_block_size(declared)
-            res = ctx.bwt(blocks, declared)
-            for blk, (bw, orig, _) in zip(blocks, res):
-                ob, oo, per = orc.bwt(blk)
-                assert np.array_equal(ob, bw) and oo == orig, (declared, blk.size, per)
-    finally:
-        orc.set_block_size(0)
+    for declared in (100000, 400000, 900000):
+        res = ctx.bwt(blocks, declared)
+        for blk, (bw, orig, _) in zip(blocks, res):
+            ob, oo, per = orc.bwt(blk, declared)
+            assert np.array_equal(ob, bw) and oo == orig, (declared, blk.size, per)
     with pytest.raises(bzip2_amd.BZ2HipError) as e:
         ctx.bwt(blocks, 150000)
     assert e.value.code == -1

@@ -136,19 +136,14 @@ def test_bwt_tiers_agree(orc):
     cases += [np.tile(rng.integers(0, a, w, dtype=np.uint8), k)
               for (a, w, k) in ((2, 2, 5000), (3, 5, 900), (256, 1000, 90), (4, 31, 2900), (256, 30000, 3))]
     cases += [rng.integers(0, a, n, dtype=np.uint8) for a in (1, 2, 4) for n in (1, 2, 3, 5, 8, 9, 1025)]
-    try:
-        for c in cases:
-            orc.set_tie_rule(0)
-            b2, o2, k2 = orc.bwt(c)
-            orc.set_tie_rule(1)
-            b1, o1, k1 = orc.bwt(c)
-            assert np.array_equal(b1, b2) and k1 == k2
-            if k1 == 1 or k1 == len(c):
-                assert o1 == o2
-            else:
-                assert o1 <= o2 < o1 + k1
-    finally:
-        orc.set_tie_rule(0)
+    for c in cases:
+        b2, o2, k2 = orc.bwt(c, tie_rule=0)
+        b1, o1, k1 = orc.bwt(c, tie_rule=1)
+        assert np.array_equal(b1, b2) and k1 == k2
+        if k1 == 1 or k1 == len(c):
+            assert o1 == o2
+        else:
+            assert o1 <= o2 < o1 + k1
 
 
 def test_divsufsort_small_exhaustive(orc):
@@ -303,3 +298,59 @@ def test_seed_backoff_follows_the_java_original_d23(orc):
         got[java_order] = np.stack([orc.huffman_code_lengths(tf[t].astype(np.int32), alpha) for t in range(nt)])
     assert not np.array_equal(got[True], got[False])      # the input tells the two readings apart
     assert np.array_equal(got[True], iters[0][:nt, :alpha])  # the oracle follows the Java original
+
+
+def test_declared_block_size_is_an_argument_not_process_state(orc):
+    """tier 2 sorts inside an int array of declared block size + 1 entries
+    (S/BZip2BlockCompressor.swift:318).  The size and the tie rule are arguments of every oracle
+    entry point: single- and multi-threaded streams size the array identically, in any call order
+    and at any level mix."""
+    rng = np.random.default_rng(77)
+    inputs = {"w5": np.tile(np.array([0, 0, 1, 2, 0], dtype=np.uint8), 9000),
+              "w31": np.tile(rng.integers(0, 4, 31, dtype=np.uint8), 3200),
+              "abc33": np.tile(np.frombuffer(b"abc", dtype=np.uint8), 33)}
+    seen = {}
+    for order in ((1, 8), (8, 1)):
+        for level in (9, 1, 5, 1, 9):       # levels interleaved: nothing may stick from an earlier call
+            for name, d in inputs.items():
+                for threads in order:
+                    s, nb = orc.compress(d, level, threads=threads)
+                    assert seen.setdefault((name, level), s) == s, (name, level, threads, order)
+                    assert bz2.decompress(s) == d.tobytes()
+    # the stream is what the stage entry points give with the declared size passed explicitly
+    for name, d in inputs.items():
+        for level in (1, 5, 9):
+            used, blk, pres, crc = orc.rle1_block(d, level * 100000)
+            assert used == d.size
+            _, o_decl, k = orc.bwt(blk, level * 100000)
+            assert k > 1
+            bits, nbits = orc.block_compress(blk, pres, crc, level * 100000)
+            hdr = bytes([0x42, 0x5A, 0x68, 0x30 + level])
+            body = np.unpackbits(np.frombuffer(seen[(name, level)][4:], dtype=np.uint8))[:nbits]
+            assert np.array_equal(body, np.unpackbits(bits)[:nbits]), (name, level)
+            assert seen[(name, level)][:4] == hdr
+            # origin pointer field: bits 81..104 of the block (48 magic + 32 CRC + 1 randomised)
+            assert int("".join(map(str, body[81:105])), 2) == o_decl
+
+
+def test_tier2_array_length_decides_only_whether_the_reference_would_fail(orc):
+    """What the declared size can change (searched over 150 k periodic blocks): the direct
+    read SA[ISAd + SA[a]] (S/BZip2DivSufSort.swift:2589-2592) passes the END of a tight array on
+    about one periodic block in ten -- the reference would stop with an index error there ("trap").
+    Inside the reference's real array (declared size + 1 >= 100 001 ints) the same read lands in the
+    zero tail; the restatement reads 0 in both cases, so the pointer itself never depends on the
+    declared size.  The cases below trap in an array of n + 1 ints and not in the real one."""
+    rng = np.random.default_rng(3)
+    traps = same = 0
+    for _ in range(400):
+        w = int(rng.integers(100, 400))
+        k = int(rng.integers(2, 7))
+        blk = np.tile(rng.integers(0, int(rng.choice([2, 8, 256])), w, dtype=np.uint8), k)
+        o_tight, t_tight = orc.divsufsort_raw(blk, blk.size + 1)
+        for declared in (100000, 500000, 900000):
+            o, t = orc.divsufsort_raw(blk, declared + 1)
+            assert t == 0 and o == o_tight, (w, k, declared)
+            assert orc.bwt(blk, declared)[1] == o
+            same += 1
+        traps += t_tight
+    assert traps >= 10 and same == 1200

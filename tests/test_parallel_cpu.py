@@ -41,7 +41,7 @@ class OracleEngine:
     def compress(self):
         bits_all, crcs = [], []
         for blk, pres, crc in self.blocks:
-            bits, nbits = self.orc.block_compress(blk, pres, crc)
+            bits, nbits = self.orc.block_compress(blk, pres, crc, self.level * 100000)
             bits_all.append(np.unpackbits(bits)[:nbits])
             crcs.append(crc)
         allbits = np.concatenate(bits_all)

@@ -14,10 +14,9 @@ exec(compile(src, "fuzz_gen", "exec"), ns)
 gen = ns["gen"]
 tie = int(os.environ.get("FUZZ_TIE", "1"))
 c = Context(tie_rule=tie)
-orc.set_tie_rule(tie)
 for seed in map(int, sys.argv[1:]):
     d, level = gen(seed)
-    want, nb = orc.compress(d, level)
+    want, nb = orc.compress(d, level, tie_rule=tie)
     got = c.compress(d, level)
     try:
         rt = bz2.decompress(got) == d.tobytes()
@@ -30,8 +29,8 @@ for seed in map(int, sys.argv[1:]):
     for b in range(len(ostarts)):
         used, blk, pres, cr = orc.rle1_block(d[int(ostarts[b]):], level * 100000)
         ok_rle = np.array_equal(blk, rles[b]) and cr == crc[b]
-        (gbw, go, gr), = c.bwt([blk])
-        ob, oo, ok_ = orc.bwt(blk)
+        (gbw, go, gr), = c.bwt([blk], level * 100000)
+        ob, oo, ok_ = orc.bwt(blk, level * 100000, tie)
         eqb = np.array_equal(gbw, ob)
         print(f"  block {b}: n={blk.size} rle_ok={ok_rle} bwt_eq={eqb} orig {go}/{oo} rounds={gr} k={ok_}")
         if not eqb:

@@ -46,13 +46,13 @@ def gen(seed):
     return d, int(rng.integers(1, 10))
 
 first, count = int(sys.argv[1]), int(sys.argv[2])
-c = Context(tie_rule=int(os.environ.get("FUZZ_TIE", "0")))
-orc.set_tie_rule(int(os.environ.get("FUZZ_TIE", "0")))
+TIE = int(os.environ.get("FUZZ_TIE", "0"))
+c = Context(tie_rule=TIE)
 bad = 0
 t0 = time.time()
 for seed in range(first, first + count):
     d, level = gen(seed)
-    want, _ = orc.compress(d, level)
+    want, _ = orc.compress(d, level, tie_rule=TIE)
     got = c.compress(d, level)
     if got != want:
         bad += 1

@@ -14,7 +14,6 @@ exec(compile(src, "fuzz_gen", "exec"), ns)
 gen = ns["gen"]
 
 first, count = int(sys.argv[1]), int(sys.argv[2])
-orc.set_tie_rule(1)
 ctxs = {}
 def ctx_for(batch):
     if batch not in ctxs:
@@ -29,7 +28,7 @@ for seed in range(first, first + count):
         d = np.concatenate([d, d[::-1], d[: d.size // 2]])
         level = 1 + seed % 3
     rng = np.random.default_rng(seed ^ 0xABCDEF)
-    want, _ = orc.compress(d, level)
+    want, _ = orc.compress(d, level, tie_rule=1)
     mode = seed % 4
     if mode == 0:      # streaming, ragged writes
         c = ctx_for(0)
