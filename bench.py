@@ -11,9 +11,13 @@ N > 1: ONE stream of N x 256 MiB of the `stream1g` generator (config 4; N = 4 is
        stream) sharded over the ranks: every rank holds its byte range (+ lookahead) in HBM and
        scans it, the block chain hops from rank to rank (one integer), every rank compresses its
        blocks, rank 0 gathers the bit segments and concatenates them in order on its GPU.  Scan,
-       chain, compression, gather and stitch are all inside the timed region; rank 0 then checks
-       the stream against the one it compresses alone from the same data (SHA-256) and through
-       the GPU decoder.  Per-GPU work is fixed as N grows ("weak").
+       chain, compression, gather and stitch are all inside the timed region (`ship` = rank 0's
+       gather + stitch time per stream).  After the clock rank 0 also runs the same stream through
+       the OTHER front end, one process driving all N GPUs through bz2hip_opts.devices[] from host
+       buffers (`in_process`), and checks the timed stream against it, against a single-GPU stream
+       and through the GPU decoder.  Per-GPU work is fixed as N grows ("weak").
+       `python bench.py --gpus N` without a launcher starts its own N ranks (a child
+       torch.distributed.run); under a launcher whose world is not N it exits non-zero.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel by
 GPU time) and, at N = 1, `cpu_baseline` (the CPU oracle timed on a bounded sample of the same
@@ -48,6 +52,39 @@ def load_pmc():
     return None, {}
 
 
+def launch_decision(gpus, env):
+    """What `bench.py --gpus N` does before anything touches torch or the GPU.
+    -> ("run", None): this process is the single rank, or one rank of the right world;
+       ("spawn", None): N > 1 and no launcher -> bench.py starts torch.distributed.run itself;
+       ("error", message): launched with a world that is not N -> exit non-zero (never a line
+       that says n_gpus: 1 for a --gpus 8 request)."""
+    ws = env.get("WORLD_SIZE")
+    if ws is None and env.get("RANK") is None:
+        return ("run", None) if gpus <= 1 else ("spawn", None)
+    try:
+        world = int(ws if ws is not None else "1")
+    except ValueError:
+        return ("error", f"WORLD_SIZE={ws!r} is not a number")
+    if world != max(gpus, 1):
+        return ("error", f"--gpus {gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus {gpus}` "
+                         f"(it launches its own ranks) or with --nproc-per-node {gpus}")
+    return ("run", None)
+
+
+def spawn_ranks(gpus, argv):
+    """One process per GPU as a CHILD process (never exec: this pool forbids replacing a process, and
+    nothing here has touched the GPU yet anyway); its stdout -- the one JSON line -- passes through."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print(f"[bench] no launcher in the environment: starting {gpus} ranks: {' '.join(cmd)}", file=sys.stderr)
+    return subprocess.run(cmd).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -63,6 +100,12 @@ def main():
     ap.add_argument("--profile-all", action="store_true",
                     help="HIP events around every kernel class (adds ~2 ms per step of event overhead)")
     args = ap.parse_args()
+    what, msg = launch_decision(args.gpus, os.environ)
+    if what == "error":
+        print(f"[bench] {msg}", file=sys.stderr)
+        sys.exit(2)
+    if what == "spawn":
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     # stdout carries the ONE JSON line and nothing else: libraries write there too (gloo prints its
     # connection notices on stdout), so file descriptor 1 is pointed at stderr and the JSON line is
     # written to the saved descriptor at the end
@@ -77,21 +120,27 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and rank == 0:
-        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE {world}: launch with torch.distributed.run "
-              f"--nproc-per-node {args.gpus}; running with {world} rank(s)", file=sys.stderr)
     # rehearsal on a one-GPU box: BZ2_BENCH_BACKEND=gloo BZ2_BENCH_ONE_GPU=1 puts every rank on cuda:0
     backend = os.environ.get("BZ2_BENCH_BACKEND", "nccl")
     if os.environ.get("BZ2_BENCH_ONE_GPU"):
         local_rank = 0
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    seg_group = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # The default group is gloo (host transport): the chain hop, sizes, CRCs, barriers and the
+        # timing reduction are a few bytes each and must work whatever the state of RCCL.  RCCL
+        # carries only the bit segments (GPU to GPU); its group is created lazily and probed before
+        # the warm-up, and if creating or probing it raises on ANY rank every rank falls back to host
+        # transport for the segments too (config.segment_transport says which one ran).
+        dist.init_process_group(backend="gloo")
+        if backend == "nccl":
+            try:
+                seg_group = dist.new_group(backend="nccl")
+            except Exception as ex:
+                print(f"[bench] rank {rank}: RCCL group could not be created ({ex!r})", file=sys.stderr)
+                seg_group = None
 
     from bzip2_amd import Context, PinnedBuffer, corpus, parallel
 
@@ -155,7 +204,7 @@ def main():
             cap = L.bz2hip_compress_bound(n_total)
             d_out = torch.empty(cap + 64, dtype=torch.uint8, device=dev)
             ctx_stitch = Context(device=local_rank, profile=0)
-        cpu_comm = backend != "nccl"
+        cpu_comm = seg_group is None
         hop_t = torch.zeros(1, dtype=torch.int64)
         MAXCRC = n_in // (level * 50000) + 16
 
@@ -177,7 +226,10 @@ def main():
             ev.record()
             ev.synchronize()
 
+        ship_times = []  # rank 0: (gather seconds, stitch seconds) per stream
+
         def ship(eng, seg):
+            t_ship = time.perf_counter()
             d_seg, nbits, crcs = seg
             # gather: sizes + CRCs (host, tiny), then the bit segments (device to device)
             meta = torch.zeros(2 + MAXCRC, dtype=torch.int64)
@@ -202,18 +254,21 @@ def main():
                             dist.recv(buf, src=r, group=meta_group)
                             d_recv[r][:k].copy_(buf)
                         else:
-                            ops.append(dist.P2POp(dist.irecv, d_recv[r][:k], r))
+                            ops.append(dist.P2POp(dist.irecv, d_recv[r][:k], r, group=seg_group))
                     segs.append((d_recv[r].data_ptr(), nb_r, cr))
                 if ops:
                     for w in dist.batch_isend_irecv(ops):
                         w.wait()
                 wait_current_stream()
-                return ctx_stitch.stitch_device(level, segs, d_out.data_ptr(), cap)
+                t_got = time.perf_counter()
+                n_out = ctx_stitch.stitch_device(level, segs, d_out.data_ptr(), cap)  # returns with the stream complete
+                ship_times.append((t_got - t_ship, time.perf_counter() - t_got))
+                return n_out
             if nbytes:
                 if cpu_comm:
                     dist.send(d_seg[:nbytes].cpu(), dst=0, group=meta_group)
                 else:
-                    for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, d_seg[:nbytes], 0)]):
+                    for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, d_seg[:nbytes], 0, group=seg_group)]):
                         w.wait()
                     wait_current_stream()  # the segment has left before its buffer is reused
             return 0
@@ -229,10 +284,7 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            if cpu_comm:
-                dist.barrier(group=meta_group)
-            else:
-                dist.barrier()
+            dist.barrier(group=meta_group)
         torch.cuda.synchronize()
 
     transport = None
@@ -252,20 +304,20 @@ def main():
             dist.recv(z, src=rank - 1, group=hop_group)
         if rank + 1 < world:
             dist.send(z, dst=rank + 1, group=hop_group)
-        if cpu_comm:
-            if rank == 0:
-                for r in range(1, world):
-                    dist.recv(z, src=r, group=meta_group)
-            else:
-                dist.send(z, dst=0, group=meta_group)
+        # the host path for segments is opened in any case (it is the fall-back)
+        if rank == 0:
+            for r in range(1, world):
+                dist.recv(z, src=r, group=meta_group)
         else:
-            ok = 1
+            dist.send(z, dst=0, group=meta_group)
+        ok = 0 if seg_group is None else 1
+        if seg_group is not None:
             try:
                 dz = torch.zeros(8, dtype=torch.uint8, device=dev)
                 if rank == 0:
-                    ops = [dist.P2POp(dist.irecv, d_recv[r][:8], r) for r in range(1, world)]
+                    ops = [dist.P2POp(dist.irecv, d_recv[r][:8], r, group=seg_group) for r in range(1, world)]
                 else:
-                    ops = [dist.P2POp(dist.isend, dz, 0)]
+                    ops = [dist.P2POp(dist.isend, dz, 0, group=seg_group)]
                 for w in dist.batch_isend_irecv(ops):
                     w.wait()
                 torch.cuda.synchronize()
@@ -273,10 +325,10 @@ def main():
                 ok = 0
                 print(f"[bench] rank {rank}: RCCL point-to-point set-up failed ({ex!r}); "
                       f"segments will be gathered through host memory (gloo)", file=sys.stderr)
-            flag = torch.tensor([ok], dtype=torch.int64)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=meta_group)
-            if int(flag.item()) == 0:
-                cpu_comm = True
+        flag = torch.tensor([ok], dtype=torch.int64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=meta_group)
+        if int(flag.item()) == 0:
+            cpu_comm = True
         transport = ("host memory (gloo)" if cpu_comm else "RCCL point-to-point, GPU to GPU")
     out_len = run_streams(args.warmup)
     ctx.profile_reset()
@@ -286,14 +338,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        pipe.close()
-    if world > 1:
-        if cpu_comm:
-            t = torch.tensor([dt], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=meta_group)
-        else:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=meta_group)
         dt = float(t.item())
 
     stats = ctx.last_stats()
@@ -301,32 +347,92 @@ def main():
     # streams the profiled context handled inside the timed region (N > 1: every second one)
     prof_steps = args.steps if world == 1 else max(1, sum(1 for j in range(args.warmup, args.warmup + args.steps) if j % 2 == 0))
 
-    # correctness guard on rank 0 (outside the timed region)
-    check = {}
-    if rank == 0:
-        comp = d_out[:out_len].cpu().numpy().tobytes()
-        if world == 1:
-            import bz2
-            try:
-                check["roundtrip_ok"] = bz2.decompress(comp) == data.tobytes()
-            except (OSError, ValueError):
-                check["roundtrip_ok"] = False
+    # ---- after the clock (N > 1): the whole input goes to rank 0's host memory (every rank sends the
+    # bytes of its nominal range over gloo: nobody regenerates another rank's data), and rank 0
+    #   * times the OTHER front end of the same path: ONE process, Context(devices=[0..N-1]),
+    #     bz2hip_compress from and to page-locked host buffers -- a worker thread and a block queue per
+    #     GPU, ordered concatenation on the calling thread (S/BZip2OutputStream.swift:29,94-102,131-141);
+    #     PCIe both ways is inside that clock, so it is reported beside `value`, never as `value`;
+    #   * checks the stream of the timed region: SHA-256 against the in-process stream, the GPU decoder's
+    #     round trip, and against a single-GPU stream of the same bytes (whole up to 512 MiB, else the
+    #     first 256 MiB cut at a block boundary: the streams agree up to the shorter one's trailer).
+    check, in_process = {}, None
+    if world > 1:
+        ship_stats = None
+        if rank == 0 and ship_times:
+            tail = ship_times[-args.steps:] if args.steps else ship_times
+            ship_stats = {"gather_ms": round(sum(t[0] for t in tail) / len(tail) * 1e3, 3),
+                          "stitch_ms": round(sum(t[1] for t in tail) / len(tail) * 1e3, 3)}
+        pipe.close()
+        pipe = None
+        for e in engs:
+            e.d_out = None
+        ctxs[1].close()
+        if rank == 0:
+            pin_whole = PinnedBuffer(n_total)
+            pin_whole.a[lo:hi] = mine[: hi - lo]
+            for r in range(1, world):
+                rlo, rhi = parallel.nominal_ranges(n_total, world)[r]
+                dist.recv(torch.from_numpy(pin_whole.a[rlo:rhi]), src=r, group=meta_group)
         else:
-            # the same data as one stream on this GPU alone: must be the same bytes
-            whole = corpus.mixed(world * seg, corpus.STREAM1G_SEED)
-            d_whole = torch.from_numpy(whole).to(dev)
-            c1 = Context(device=local_rank)
-            cap1 = L.bz2hip_compress_bound(n_total)
-            d_one = torch.empty(cap1 + 64, dtype=torch.uint8, device=dev)
-            n1 = c1.compress_device(d_whole.data_ptr(), n_total, level, d_one.data_ptr(), cap1)
-            one = d_one[:n1].cpu().numpy().tobytes()
-            check["sha256"] = hashlib.sha256(comp).hexdigest()
-            check["equals_single_gpu_stream"] = (hashlib.sha256(one).hexdigest() == check["sha256"])
-            d_back = torch.empty(n_total + 64, dtype=torch.uint8, device=dev)
-            drc, dn = c1.decompress_device(d_out.data_ptr(), out_len, d_back.data_ptr(), n_total)
-            check["roundtrip_ok"] = bool(drc == 0 and dn == n_total and torch.equal(d_back[:dn], d_whole))
-            c1.close()
-            del d_whole, d_one, d_back
+            dist.send(torch.from_numpy(mine[: hi - lo]), dst=0, group=meta_group)
+    if rank == 0 and world > 1:
+        comp = d_out[:out_len].cpu().numpy().tobytes()
+        check["sha256"] = hashlib.sha256(comp).hexdigest()
+        one_gpu = bool(os.environ.get("BZ2_BENCH_ONE_GPU"))
+        devices = [0] * world if one_gpu else list(range(world))
+        try:
+            cap_w = L.bz2hip_compress_bound(n_total)
+            pin_out = PinnedBuffer(cap_w)
+            ctx_ip = Context(devices=devices, max_batch_blocks=args.batch, profile=0)
+            got = ctx_ip.compress_into(pin_whole.a, level, pin_out.a)  # allocates the workspaces
+            k_ip = max(1, min(args.steps, 5))
+            th = time.perf_counter()
+            for _ in range(k_ip):
+                got = ctx_ip.compress_into(pin_whole.a, level, pin_out.a)
+            th = (time.perf_counter() - th) / k_ip
+            in_process = {"value": round(n_total / th / 1e6, 1), "unit": "MB/s", "ms_per_step": round(th * 1e3, 2),
+                          "steps": k_ip, "devices": devices,
+                          "what": "one process, bz2hip_opts.devices[]: host buffer in, host buffer out (PCIe inside the clock)",
+                          "same_bytes": bool(got == out_len and
+                                             hashlib.sha256(pin_out.a[:got].tobytes()).hexdigest() == check["sha256"])}
+            ctx_ip.close()
+            pin_out.free()
+        except Exception as ex:  # reported, never silently dropped
+            in_process = {"error": repr(ex)}
+        # single-GPU stream of the same bytes
+        c1 = Context(device=local_rank)
+        if n_total <= (512 << 20):
+            k_cut, how = n_total, "whole stream"
+        else:
+            d_head = torch.from_numpy(pin_whole.a[: (320 << 20)]).to(dev)
+            c1.shard_scan(d_head.data_ptr(), int(d_head.numel()), level)
+            _, k_cut = c1.shard_chain(0, 256 << 20, False)
+            how = f"first {k_cut} bytes (a block boundary): equal up to the shorter stream's trailer"
+            del d_head
+        d_head = torch.from_numpy(pin_whole.a[:k_cut]).to(dev)
+        cap1 = L.bz2hip_compress_bound(k_cut)
+        d_one = torch.empty(cap1 + 64, dtype=torch.uint8, device=dev)
+        n1 = c1.compress_device(d_head.data_ptr(), k_cut, level, d_one.data_ptr(), cap1)
+        one = d_one[:n1].cpu().numpy().tobytes()
+        check["equals_single_gpu_stream"] = (one == comp) if k_cut == n_total else (one[: n1 - 11] == comp[: n1 - 11])
+        check["single_gpu_check"] = how
+        del d_head, d_one
+        # the GPU decoder returns the input
+        d_whole = torch.from_numpy(pin_whole.a).to(dev)
+        d_back = torch.empty(n_total + 64, dtype=torch.uint8, device=dev)
+        drc, dn = c1.decompress_device(d_out.data_ptr(), out_len, d_back.data_ptr(), n_total)
+        check["roundtrip_ok"] = bool(drc == 0 and dn == n_total and torch.equal(d_back[:dn], d_whole))
+        c1.close()
+        del d_whole, d_back
+        pin_whole.free()
+    elif rank == 0:
+        import bz2
+        comp = d_out[:out_len].cpu().numpy().tobytes()
+        try:
+            check["roundtrip_ok"] = bz2.decompress(comp) == data.tobytes()
+        except (OSError, ValueError):
+            check["roundtrip_ok"] = False
 
     res = None
     if rank == 0:
@@ -350,6 +456,9 @@ def main():
                        "compressed_bytes": out_len, "parallelism": f"blocks-sharded x{world}",
                        **({"segment_transport": transport} if transport else {}), **check},
         }
+        if world > 1:
+            res["ship"] = ship_stats       # rank 0's share per stream inside the clock: receive + stitch
+            res["in_process"] = in_process  # the same streams through ONE process driving all N GPUs
         if prof:
             # dominant kernel class = the one with the most GPU time among those with a defined
             # algorithmic byte count
