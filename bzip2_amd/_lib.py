@@ -25,7 +25,7 @@ SYMBOLS = [
     "bz2hip_last_stats", "bz2hip_last_stats2", "bz2hip_decompress", "bz2hip_decompress_device",
     "bz2hip_compress_device_noalloc", "bz2hip_shard_scan", "bz2hip_shard_chain",
     "bz2hip_shard_compress", "bz2hip_stitch_device", "bz2hip_host_alloc", "bz2hip_host_free",
-    "bz2hip_tie_stats", "bz2hip_decode_consumed",
+    "bz2hip_tie_stats", "bz2hip_tie_stats2", "bz2hip_decode_consumed",
 ]
 
 
@@ -125,6 +125,8 @@ def load():
     L.bz2hip_decode_consumed.argtypes = [vp, C.POINTER(sz)]
     L.bz2hip_tie_stats.restype = C.c_int
     L.bz2hip_tie_stats.argtypes = [vp, vp, vp, vp]
+    L.bz2hip_tie_stats2.restype = C.c_int
+    L.bz2hip_tie_stats2.argtypes = [vp, vp]
     L.bz2hip_host_alloc.restype = C.c_int
     L.bz2hip_host_alloc.argtypes = [C.POINTER(vp), sz]
     L.bz2hip_host_free.restype = None
@@ -465,7 +467,9 @@ class Context:
         """periodic blocks since the context was created: replays run, results reused, cached keys"""
         v = [C.c_uint64(0) for _ in range(3)]
         self.L.bz2hip_tie_stats(self.h, *[C.byref(x) for x in v])
-        return {"replays": v[0].value, "reused": v[1].value, "cached_keys": v[2].value}
+        rej = C.c_uint64(0)
+        self.L.bz2hip_tie_stats2(self.h, C.byref(rej))
+        return {"replays": v[0].value, "reused": v[1].value, "cached_keys": v[2].value, "rejected": rej.value}
 
     def last_stats(self):
         v = [C.c_uint64(0) for _ in range(4)]

@@ -103,6 +103,7 @@ static void ensure_batch(bz2hip_ctx *c, int level, int nb_needed) {
     int cap = c->opts.max_batch_blocks > 0 ? c->opts.max_batch_blocks : DEFAULT_BATCH_BLOCKS;
     int want = std::min(cap, std::max(nb_needed, 1));
     if (B.NB >= want && B.S == S) return;
+    c->sh_state = 0; // the workspace a shard scan sized is about to be replaced
     want = std::max(want, B.S == S ? B.NB : 0);
     // free the old batch (window scratch is tracked separately); the context holds an empty batch
     // (NB = 0) until the new region exists, so a failed allocation cannot leave stale capacities
@@ -298,6 +299,7 @@ extern "C" int bz2hip_create(bz2hip_ctx **out, const bz2hip_opts *opts) {
     c->r0_sweeps = (u32)std::min(16, std::max(1, env_int("BZ2HIP_RSWEEPS", 2)));
     c->radix_bits = env_int("BZ2HIP_RADIX_BITS", 8) == 10 ? 10u : 8u;
     c->radix_stage = env_int("BZ2HIP_RADIX_STAGE", 1) != 0;
+    c->tie_poison = env_int("BZ2HIP_TIE_POISON", 0) != 0; // tests: cached origin pointers are stored wrong
     c->stream_chunk = (size_t)std::max(1, env_int("BZ2HIP_STREAM_CHUNK_MIB", (int)(STREAM_CHUNK >> 20))) << 20;
     c->stream_sync = env_int("BZ2HIP_STREAM_SYNC", 0) != 0;
     c->stream_least = (size_t)std::max(0, env_int("BZ2HIP_STREAM_LEAST_MIB", 0)) << 20;
@@ -423,6 +425,10 @@ static bool prepare_window(bz2hip_ctx *c, const u8 *d_win, size_t wlen, int leve
         c->swap_lane();
     }
     ensure_window(c, wlen, level);
+    // the window scratch (run records, prefixes, aggregates, block starts) is overwritten now: a
+    // scan kept from bz2hip_shard_scan is gone (bz2hip_shard_chain / _compress then say E_STATE
+    // instead of walking another input's records); bz2hip_shard_scan sets the state after this call
+    c->sh_state = 0;
     run_scan(c, d_win, (u32)wlen, c->w_rs, c->w_P, c->w_agg1, c->w_agg2);
     return two;
 }
@@ -571,10 +577,11 @@ extern "C" int bz2hip_compress_device(bz2hip_ctx *c, const void *d_in, size_t n,
 }
 
 // ------------------------------------------------------------------ allocation-free variant
-// bz2hip_compress_device for callers that cannot allocate (code under HIP graph capture, tight
-// serving loops, harnesses that forbid hipMalloc): the whole workspace (K1 window scratch + one
-// batch) is carved from this GPU's copy of the static `scratch` array.  No hipMalloc / hipFree
-// on this path; events and streams were created by bz2hip_create.  Every call on a GPU shares
+// bz2hip_compress_device for callers that cannot allocate device memory (tight serving loops,
+// harnesses that forbid hipMalloc): the whole workspace (K1 window scratch + one batch) is carved
+// from this GPU's copy of the static `scratch` array.  No hipMalloc / hipFree on this path; events
+// and streams were created by bz2hip_create.  NOT capturable into a HIP graph: the path makes
+// blocking host round trips (block chain read-back, round control words, bit cursor).  Every call on a GPU shares
 // that GPU's array, so calls that overlap on one GPU (two contexts, two threads) race.
 extern "C" int bz2hip_compress_device_noalloc(bz2hip_ctx *c, const void *d_in, size_t n, int level,
                                               void *d_out, size_t cap, size_t *out_len) {
@@ -1833,6 +1840,14 @@ extern "C" int bz2hip_tie_stats(bz2hip_ctx *c, uint64_t *replays, uint64_t *reus
     if (replays) *replays = r;
     if (reused) *reused = u;
     if (cached_keys) *cached_keys = k;
+    return BZ2HIP_OK;
+}
+
+extern "C" int bz2hip_tie_stats2(bz2hip_ctx *c, uint64_t *rejected) {
+    if (!c) return BZ2HIP_E_PARAM;
+    u64 r = c->st_tie_rejected;
+    for (bz2hip_ctx *p : c->peers) r += p->st_tie_rejected;
+    if (rejected) *rejected = r;
     return BZ2HIP_OK;
 }
 

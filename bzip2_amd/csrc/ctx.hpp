@@ -49,8 +49,13 @@ struct Carver {
 struct TieKey {
     u32 level, n, k;
     u64 h1, h2;
+    u64 w[8]; // the first 64 bytes of the period word, zero-padded: words up to 64 bytes compare exactly
     bool operator<(const TieKey &o) const {
-        return std::tie(level, n, k, h1, h2) < std::tie(o.level, o.n, o.k, o.h1, o.h2);
+        if (std::tie(level, n, k, h1, h2) != std::tie(o.level, o.n, o.k, o.h1, o.h2))
+            return std::tie(level, n, k, h1, h2) < std::tie(o.level, o.n, o.k, o.h1, o.h2);
+        for (int i = 0; i < 8; i++)
+            if (w[i] != o.w[i]) return w[i] < o.w[i];
+        return false;
     }
 };
 struct TieItem {
@@ -174,6 +179,8 @@ struct bz2hip_ctx {
     hipEvent_t ev_tie = nullptr;
     std::map<TieKey, u32> tie_cache;   // origin pointers of periodic blocks seen so far
     u64 st_tie_replays = 0, st_tie_cached = 0; // since the context was created
+    u64 st_tie_rejected = 0;           // reused pointers that failed the in-class check and were replayed
+    bool tie_poison = false;           // BZ2HIP_TIE_POISON (tests): store wrong pointers in the cache
     size_t w_cap = 0;        // window capacity in input bytes
     u32 w_maxblocks = 0;
     u32 w_ETPB = 0;          // emit tiles per block slot

@@ -1179,8 +1179,12 @@ static __device__ int constructBWT(dss_t *D, int *bucketA, int *bucketB) {
 // The replay's result is a pure function of (period word w, k, declared block size): identical
 // periodic blocks -- every full block of "ab...", of zeros, of any repeated unit -- need it once.
 // Two independent 64-bit sums over the period word (position-mixed, order-independent so that a
-// wave can add them in any order) identify w; the context caches origin pointers by
-// (level, n, k, hash) and a batch runs one replay per distinct key it has not seen.
+// wave can add them in any order) plus the first 64 bytes of w itself identify w (a word of up to
+// 64 bytes -- "ab", zeros, "abc", every short unit -- is compared exactly, no hash involved); the
+// context caches origin pointers by (level, n, k, hashes, head of w) and a batch runs one replay per
+// distinct key it has not seen.  A reused pointer is never trusted: k2_tie_verify checks every
+// periodic block of the batch against the parallel sort's rank of rotation 0 (run_tie_finish).
+constexpr u32 TIE_REC = 10; // u64 words per block: h1, h2, w[0..64)
 __device__ __forceinline__ u64 mix64(u64 x) {
     x += 0x9E3779B97F4A7C15ull;
     x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -1214,9 +1218,37 @@ __global__ __launch_bounds__(256) void k2_tie_hash(const u32 *__restrict__ nArr,
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        hash[2 * b] = s1[0];
-        hash[2 * b + 1] = s2[0];
+        hash[TIE_REC * b] = s1[0];
+        hash[TIE_REC * b + 1] = s2[0];
     }
+    if (threadIdx.x < 8) { // the first 64 bytes of w, zero-padded (exact identity for |w| <= 64)
+        u64 v = 0;
+        for (u32 j = 0; j < 8; j++) {
+            const u32 i = threadIdx.x * 8 + j;
+            if (i < p) v |= (u64)t[i] << (8 * j);
+        }
+        hash[TIE_REC * b + 2 + threadIdx.x] = v;
+    }
+}
+
+// Every periodic block of the batch, whatever the source of its pointer (replay, cache, twin): the
+// pointer must name one of the k rotations equal to rotation 0, which occupy the sorted positions
+// [rank(0), rank(0) + k) of the parallel sort.  flag[b] = 1 and ctlw[2]++ where it does not.
+__global__ __launch_bounds__(256) void k2_tie_verify(const u32 *__restrict__ nArr,
+                                                     const u32 *__restrict__ periodic,
+                                                     const u32 *__restrict__ rank,
+                                                     const u32 *__restrict__ orig, u32 *__restrict__ flag,
+                                                     u32 *__restrict__ ctlw, u32 S, u32 nb) {
+    const u32 b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nb) return;
+    const u32 n = nArr[b], k = periodic[b];
+    u32 bad = 0;
+    if (k > 1 && k < n) {
+        const u32 r0 = rank[(size_t)b * S], o = orig[b];
+        bad = (o < r0 || o >= r0 + k) ? 1u : 0u;
+    }
+    flag[b] = bad;
+    if (bad) atomicAdd(&ctlw[2], 1u);
 }
 
 // One workgroup (one wave) per block that is marked in `todo`.  Scratch comes from the sort buffers,
@@ -1286,14 +1318,14 @@ void run_tie_launch(bz2hip_ctx *c, int nb) {
     B.tie_items.clear();
     B.tie_running = false;
     u64 *d_hash = (u64 *)B.pvote;                 // votes are dead after the first doubling round
-    u32 *d_todo = B.pvote + 4 * (size_t)B.NB;     // [NB] behind the hashes ([NB][2] u64)
+    u32 *d_todo = B.pvote + 2 * TIE_REC * (size_t)B.NB; // [NB] behind the records ([NB][TIE_REC] u64)
     k2_tie_hash<<<nb, 256, 0, c->stream>>>(B.n, B.periodic, B.T, d_hash, B.S);
     KCHECK();
     std::vector<u32> hn(nb), hk(nb);
-    std::vector<u64> hh((size_t)nb * 2);
+    std::vector<u64> hh((size_t)nb * TIE_REC);
     HIPCHK(hipMemcpyAsync(hn.data(), B.n, nb * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(hk.data(), B.periodic, nb * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(hh.data(), d_hash, (size_t)nb * 2 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(hh.data(), d_hash, (size_t)nb * TIE_REC * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     std::vector<u32> todo(nb, 0);
     std::map<TieKey, int> first_in_batch; // key -> block that runs the replay
@@ -1302,7 +1334,8 @@ void run_tie_launch(bz2hip_ctx *c, int nb) {
         if (hk[b] <= 1 || hk[b] >= hn[b]) continue;
         TieItem it;
         it.block = b;
-        it.key = TieKey{(u32)B.level, hn[b], hk[b], hh[2 * (size_t)b], hh[2 * (size_t)b + 1]};
+        const u64 *rec = &hh[TIE_REC * (size_t)b];
+        it.key = TieKey{(u32)B.level, hn[b], hk[b], rec[0], rec[1], {rec[2], rec[3], rec[4], rec[5], rec[6], rec[7], rec[8], rec[9]}};
         auto hit = c->tie_cache.find(it.key);
         if (hit != c->tie_cache.end()) {
             it.rep = -1;
@@ -1368,7 +1401,7 @@ void run_tie_finish(bz2hip_ctx *c, int nb) {
     for (TieItem &it : B.tie_items)
         if (it.rep == it.block) {
             it.orig = ho[it.block];
-            c->tie_cache[it.key] = it.orig;
+            c->tie_cache[it.key] = c->tie_poison ? it.orig + it.key.k : it.orig; // poison: tests only
         }
     for (TieItem &it : B.tie_items)
         if (it.rep >= 0 && it.rep != it.block) it.orig = ho[it.rep];
@@ -1376,6 +1409,41 @@ void run_tie_finish(bz2hip_ctx *c, int nb) {
     for (const TieItem &it : B.tie_items)
         if (it.rep != it.block)
             HIPCHK(hipMemcpyAsync(B.orig + it.block, &it.orig, sizeof(u32), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream)); // the sources are host temporaries
+    // No pointer goes into a block header unchecked: cache hits and twins included (a colliding key
+    // would otherwise emit a stream that decodes to a rotation of the block, silently).
+    u32 *d_flag = B.pvote + 2 * TIE_REC * (size_t)B.NB;
+    HIPCHK(hipMemsetAsync(B.ctl + 13, 0, 3 * sizeof(u32), c->stream));
+    k2_tie_verify<<<(nb + 255) / 256, 256, 0, c->stream>>>(B.n, B.periodic, B.rank, B.orig, d_flag, B.ctl + 13, B.S, (u32)nb);
+    KCHECK();
+    u32 h[3];
+    HIPCHK(hipMemcpyAsync(h, B.ctl + 13, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream)); // also: the patch sources above are host temporaries
+    if (h[2]) {
+        // a reused pointer is outside the class of rotation 0: forget those keys and replay the
+        // blocks themselves (d_flag is the todo list; the sort buffers are still dead, rank alive)
+        std::vector<u32> flag(nb);
+        HIPCHK(hipMemcpy(flag.data(), d_flag, nb * sizeof(u32), hipMemcpyDeviceToHost));
+        for (const TieItem &it : B.tie_items)
+            if (flag[it.block]) {
+                c->tie_cache.erase(it.key);
+                c->st_tie_rejected++;
+                c->st_tie_replays++;
+            }
+        HIPCHK(hipMemsetAsync(B.ctl + 13, 0, 3 * sizeof(u32), c->stream));
+        {
+            ProfScope ps(c, P_BWT_TIE);
+            k2_tie_divsufsort<<<nb, 64, 0, c->stream>>>(B.n, B.periodic, d_flag, B.T, B.bwt, B.rank, B.keyA, B.keyB,
+                                                        B.orig, B.ctl + 13, B.S, (u32)B.level * 100000u);
+        }
+        KCHECK();
+        HIPCHK(hipMemcpyAsync(h, B.ctl + 13, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(ho.data(), B.orig, nb * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (h[1] || h[2])
+            throw HipError(BZ2HIP_E_HIP, "internal: replay of a periodic block after a rejected cached origin pointer failed its checks");
+        c->st_tie_traps += h[0];
+        for (const TieItem &it : B.tie_items)
+            if (flag[it.block]) c->tie_cache[it.key] = c->tie_poison ? ho[it.block] + it.key.k : ho[it.block];
+    }
     B.tie_items.clear();
 }

@@ -1248,8 +1248,11 @@ int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size
     const u32 block_size = (u32)level * 100000u;
     const u32 S = ((block_size + 64 + RTILE - 1) / RTILE) * RTILE;
 
-    // a block is at least ~ 130 bits long: the scan cannot find more real blocks than this
-    const u32 cand_cap = (u32)std::min<u64>(nbytes / 8 + 16, 1u << 24);
+    // A real block is at least ~ 130 bits long, so a well-formed stream has fewer magics than this;
+    // a crafted one can repeat the 48-bit magic every 45 bits (it overlaps itself by 3).  The scan
+    // counts every hit even when the list is full: on overflow the list is regrown to the count and
+    // the scan repeated, so such input gets the reference's error for its first block, not NOMEM.
+    u32 cand_cap = (u32)std::min<u64>(nbytes / 8 + 16, 1u << 24);
     // The workspace is one region kept in the context between calls (grown on demand): candidates
     // first (their number sets the batch size), then the batch arrays.
     const u32 RS = (block_size + KD_RULER - 1) / KD_RULER + 2;
@@ -1303,7 +1306,17 @@ int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size
     u32 ncand = 0;
     HIPCHK(hipMemcpyAsync(&ncand, d_ncand, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    if (ncand > cand_cap) throw HipError(BZ2HIP_E_NOMEM, "too many block magic candidates");
+    if (ncand > cand_cap) {
+        if ((u64)ncand > total_bits / 45 + 1) throw HipError(BZ2HIP_E_HIP, "internal: magic scan counted more hits than fit the input");
+        cand_cap = ncand;
+        ensure(1);
+        HIPCHK(hipMemsetAsync(d_ncand, 0, 16, st));
+        kd_scan_magic<<<(u32)((nbytes + 255) / 256), 256, 0, st>>>(d_in, nbytes, d_cand, d_ncand, cand_cap);
+        KCHECK();
+        HIPCHK(hipMemcpyAsync(&ncand, d_ncand, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (ncand > cand_cap) throw HipError(BZ2HIP_E_HIP, "internal: magic scan is not repeatable");
+    }
     std::vector<u64> cand(ncand);
     if (ncand) {
         HIPCHK(hipMemcpyAsync(cand.data(), d_cand, ncand * sizeof(u64), hipMemcpyDeviceToHost, st));

@@ -112,8 +112,10 @@ int bz2hip_compress_blocks(bz2hip_ctx *ctx, const uint8_t *in, size_t n, int lev
                            uint32_t *n_blocks);
 
 /* Allocation-free variant of bz2hip_compress_device.  It has NO counterpart in the reference: it
- * exists for callers that cannot allocate device memory -- code under HIP graph capture, tight
- * serving loops, harnesses that forbid hipMalloc.  The whole workspace is carved from a static
+ * exists for callers that cannot allocate device memory -- tight serving loops, harnesses that
+ * forbid hipMalloc.  It makes no device allocation but is NOT capturable into a HIP graph: like
+ * bz2hip_compress_device it makes synchronous read-backs (block chain, round control, bit
+ * cursor).  The whole workspace is carved from a static
  * device array of BZ2HIP_NOALLOC_SCRATCH_MIB MiB that every GPU the library runs on holds until
  * the process ends; the call makes no hipMalloc / hipFree.  n must not exceed
  * BZ2HIP_NOALLOC_MAX_INPUT (BZ2HIP_E_PARAM otherwise); output is byte-identical to
@@ -270,6 +272,12 @@ int bz2hip_last_stats3(bz2hip_ctx *ctx, double *bwt_seconds, uint64_t *tie_traps
  * blocks that reused a result (same period word, k and declared block size: from the context's
  * cache or from a twin in the same batch), keys in the cache. */
 int bz2hip_tie_stats(bz2hip_ctx *ctx, uint64_t *replays, uint64_t *reused, uint64_t *cached_keys);
+/* Every origin pointer of a periodic block -- replayed, cached or shared with a twin -- is checked on
+ * the device against the parallel sort (it must name one of the k rotations equal to rotation 0)
+ * before it is written into a block header.  rejected = reused pointers that failed that check since
+ * the context was created; their keys were dropped and the blocks replayed (0 unless two different
+ * period words collided in the cache key). */
+int bz2hip_tie_stats2(bz2hip_ctx *ctx, uint64_t *rejected);
 
 #ifdef __cplusplus
 }

@@ -94,6 +94,27 @@ def test_errors_follow_the_oracle(ctx):
         assert out == orc_out, k
 
 
+def test_back_to_back_block_magics_get_the_reference_error(ctx):
+    """the 48-bit block magic can recur every 6 bytes (every 45 bits, even: it overlaps
+    itself by 3), far more often than real blocks.  A crafted stream of nothing but magics must
+    fail like the reference (its first block is garbage), not with "too many candidates"."""
+    magic = bytes.fromhex("314159265359")
+    for n_magic in (10, 40000):
+        st = b"BZh9" + magic * n_magic
+        orc_rc, orc_out, _ = orc.decompress(st, 1 << 20)
+        rc, out = ctx.decompress(st, 1 << 20)
+        assert orc_rc != 0 and rc == MAP[orc_rc], (n_magic, rc, orc_rc)
+        assert out == orc_out
+    # packed at the 45-bit self-overlap: 0x314159265359 shifted so that its last 3 bits start the next
+    bits = format(0x314159265359, "048b")
+    packed = (bits[:45] * 30000) + bits[45:]
+    packed += "0" * (-len(packed) % 8)
+    st = b"BZh9" + int(packed, 2).to_bytes(len(packed) // 8, "big")
+    orc_rc, orc_out, _ = orc.decompress(st, 1 << 20)
+    rc, out = ctx.decompress(st, 1 << 20)
+    assert orc_rc != 0 and rc == MAP[orc_rc] and out == orc_out
+
+
 def test_bit_flip_fuzz(ctx):
     rng = np.random.default_rng(5)
     data = corpus.mixed(1, 8).tobytes()[:250000]

@@ -208,6 +208,78 @@ def test_periodic_blocks_fast_rules(orc):
         c.close()
 
 
+def test_reused_origin_pointers_are_checked_before_they_are_emitted(orc):
+    """VERDICT r2 item 6 / ADVICE: a pointer taken from the context's cache (or from a twin in the
+    batch) is verified on the device for EVERY periodic block -- rank(0) <= orig < rank(0) + k --
+    and a failing one is dropped and the block replayed.  BZ2HIP_TIE_POISON makes the cache store
+    wrong pointers (orig + k, outside the class), so every reuse must be rejected and repaired."""
+    from bzip2_amd import Context
+    os.environ["BZ2HIP_TIE_POISON"] = "1"
+    try:
+        c = Context()
+    finally:
+        del os.environ["BZ2HIP_TIE_POISON"]
+    try:
+        ins = _periodic_inputs()
+        for name in ("w31", "w5", "abc33", "w1000"):
+            d = ins[name]
+            want, _ = orc.compress(d, 9)
+            for rep in range(3):            # first: replay; then: cache hit -> rejected -> replay
+                assert c.compress(d, 9) == want, (name, rep)
+        # twins inside one batch (several blocks with the same period word) and cache hits mixed
+        d = np.tile(np.array([0, 0, 1, 2, 0], dtype=np.uint8), 100000)
+        want, nb = orc.compress(d, 1)
+        assert nb >= 4
+        for rep in range(2):
+            assert c.compress(d, 1) == want
+        st = c.tie_stats()
+        assert st["rejected"] >= 9, st
+    finally:
+        c.close()
+    # an honest context never rejects
+    c = Context()
+    try:
+        for rep in range(2):
+            assert c.compress(d, 1) == want
+        assert c.tie_stats()["rejected"] == 0 and c.tie_stats()["reused"] >= 4
+    finally:
+        c.close()
+
+
+def test_shard_state_is_invalidated_by_other_entry_points(ctx):
+    """ADVICE r2: bz2hip_shard_chain / _compress walk the window scratch bz2hip_shard_scan filled;
+    any other entry point that rescans (compress, rle1_split, a stream) must invalidate it."""
+    import torch
+    import bzip2_amd
+    d = corpus.mixed(3, 5)
+    d_in = torch.from_numpy(d).to("cuda")
+    d_out = torch.empty(ctx.L.bz2hip_compress_bound(d.size) + 64, dtype=torch.uint8, device="cuda")
+    for other in ("compress", "rle1_split", "stream", "bwt_other_level"):
+        ctx.shard_scan(d_in.data_ptr(), d.size, 9)
+        nb, nxt = ctx.shard_chain(0, d.size, True)
+        assert nb >= 3 and nxt == d.size
+        if other == "compress":
+            ctx.compress(corpus.text(50000, 1), 9)
+        elif other == "rle1_split":
+            ctx.rle1_split(corpus.text(50000, 2), 9)
+        elif other == "stream":
+            ctx.stream_begin(9); ctx.stream_write(corpus.text(50000, 3)); ctx.stream_finish()
+            while ctx.stream_pending():
+                ctx.stream_read()
+        else:
+            ctx.bwt([np.arange(200, dtype=np.uint8)], 100000)   # re-sizes the batch workspace for level 1
+        for call in (lambda: ctx.shard_chain(0, d.size, True),
+                     lambda: ctx.shard_compress(d_out.data_ptr(), d_out.numel() - 64, nb + 1)):
+            with pytest.raises(bzip2_amd.BZ2HipError) as e:
+                call()
+            assert e.value.code == -5, other
+    # and the normal sequence still works afterwards
+    ctx.shard_scan(d_in.data_ptr(), d.size, 9)
+    nb, nxt = ctx.shard_chain(0, d.size, True)
+    nbits, crcs = ctx.shard_compress(d_out.data_ptr(), d_out.numel() - 64, nb + 1)
+    assert len(crcs) == nb and nbits > 0
+
+
 def test_text900k_config2(ctx, orc):
     # BASELINE config 2: one full 900k block, byte-exact vs the oracle
     d = corpus.text900k()

@@ -54,3 +54,36 @@ def test_noalloc_rejects_sizes_beyond_the_maximum(ctx):
     # the context still works through the allocating entry point afterwards
     data = np.frombuffer(b"hello hello hello", dtype=np.uint8)
     assert bz2.decompress(ctx.compress(data, 9)) == data.tobytes()
+
+
+def test_noalloc_really_allocates_nothing():
+    """The property in the name: free device memory is the same before and after the call.  A FRESH
+    context (its own batch workspace has never been allocated, so the call cannot be living off an
+    earlier allocating call) makes one warm-up call -- the HIP runtime loads code objects and sizes
+    its private-segment scratch on first launches -- and then free memory must not move over two
+    more calls, the second with a smaller input."""
+    import torch
+    from bzip2_amd import Context, corpus
+    dev = torch.device("cuda", 0)
+    c = Context()
+    try:
+        big = corpus.mixed(1, 21)
+        small = corpus.text(70000, 22)
+        d_big = torch.from_numpy(big).to(dev)
+        d_small = torch.from_numpy(small).to(dev)
+        cap = c.L.bz2hip_compress_bound(big.size)
+        d_out = torch.empty(cap + 64, dtype=torch.uint8, device=dev)
+        n0 = c.compress_device_noalloc(d_big.data_ptr(), big.size, 9, d_out.data_ptr(), cap)   # warm-up
+        first = d_out[:n0].cpu().numpy().tobytes()
+        torch.cuda.synchronize()
+        free0, _ = torch.cuda.mem_get_info()
+        n1 = c.compress_device_noalloc(d_big.data_ptr(), big.size, 9, d_out.data_ptr(), cap)
+        free1, _ = torch.cuda.mem_get_info()
+        n2 = c.compress_device_noalloc(d_small.data_ptr(), small.size, 9, d_out.data_ptr(), cap)
+        free2, _ = torch.cuda.mem_get_info()
+        assert free1 == free0 and free2 == free0, (free0, free1, free2)
+        assert n1 == n0
+        assert bz2.decompress(first) == big.tobytes()
+        assert bz2.decompress(d_out[:n2].cpu().numpy().tobytes()) == small.tobytes()
+    finally:
+        c.close()
