@@ -226,14 +226,19 @@ def test_reused_origin_pointers_are_checked_before_they_are_emitted(orc):
             want, _ = orc.compress(d, 9)
             for rep in range(3):            # first: replay; then: cache hit -> rejected -> replay
                 assert c.compress(d, 9) == want, (name, rep)
-        # twins inside one batch (several blocks with the same period word) and cache hits mixed
-        d = np.tile(np.array([0, 0, 1, 2, 0], dtype=np.uint8), 100000)
+        assert c.tie_stats()["rejected"] == 8, c.tie_stats()
+        # twins inside one batch and cache hits mixed: a -1 block takes 99 996 bytes = 8333 periods of
+        # a 12-byte word, so every full block of this input is the same perfect power
+        d = np.tile(np.array([0, 0, 1, 2, 0, 3, 3, 1, 0, 2, 2, 1], dtype=np.uint8), 40000)
         want, nb = orc.compress(d, 1)
         assert nb >= 4
+        c.compress(d, 1)
+        st1 = c.tie_stats()
+        assert c.last_stats()["periodic_blocks"] >= 4 and st1["reused"] >= 3, st1   # one replay, twins share it
         for rep in range(2):
             assert c.compress(d, 1) == want
         st = c.tie_stats()
-        assert st["rejected"] >= 9, st
+        assert st["rejected"] >= 8 + 2 * 4, st
     finally:
         c.close()
     # an honest context never rejects

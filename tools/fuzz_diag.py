@@ -6,12 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import orc
 from bzip2_amd import Context
-import importlib.util
-spec = importlib.util.spec_from_file_location("fz", os.path.join(ROOT, "tools", "fuzz_gpu.py"))
-src = open(os.path.join(ROOT, "tools", "fuzz_gpu.py")).read().split("first, count =")[0]
-ns = {"__file__": os.path.join(ROOT, "tools", "fuzz_gpu.py")}
-exec(compile(src, "fuzz_gen", "exec"), ns)
-gen = ns["gen"]
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from fuzzgen import gen
 tie = int(os.environ.get("FUZZ_TIE", "1"))
 c = Context(tie_rule=tie)
 for seed in map(int, sys.argv[1:]):
