@@ -32,9 +32,17 @@ __global__ void k4_seed(const u32 *__restrict__ mtflen, const u32 *__restrict__ 
             while (actual < target && low_end < alpha - 1) actual += (int)f[++low_end];
             // D23: Java-original order (subtract the dropped symbol's frequency, then step back); the
             // Swift text :164-167 steps back first and subtracts the new end's frequency.  The contract
-            // follows the Java original.
-            if (low_end > low_start && i != 0 && i != tables - 1 && ((tables - i) & 1) == 0)
+            // follows the Java original.  PARITY UNPINNED at this statement:
+            // nothing runnable decides between the two readings.  -DBZ2HIP_D23_SWIFT_TEXT flips it (the
+            // expected stream under that reading is frozen in tests/golden as `d23_backoff_swift_text`).
+            if (low_end > low_start && i != 0 && i != tables - 1 && ((tables - i) & 1) == 0) {
+#ifdef BZ2HIP_D23_SWIFT_TEXT
+                low_end--;
+                actual -= (int)f[low_end];
+#else
                 actual -= (int)f[low_end--];
+#endif
+            }
             lo[i] = low_start;
             hi[i] = low_end;
             remaining -= actual;

@@ -11,6 +11,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifndef ORC_D23_SWIFT_TEXT
+#define ORC_D23_SWIFT_TEXT 0 /* 1: the Swift text's reading of the seed back-off (D23, below) */
+#endif
+
 /* ------------------------------------------------------------------ CRC32 */
 /* S/BZip2CRC32.swift:32-66: table of poly 0x04c11db7, MSB first (generated, not copied). */
 static uint32_t crc_table[256];
@@ -459,9 +463,19 @@ int orc_huffman_optimise(const uint16_t *mtf, int mtf_len, int alpha, const int3
          * step back).  The Swift text (S/BZip2HuffmanStageEncoder.swift:164-167) steps back first and
          * subtracts the NEW end's frequency, and keeps no Java comment there; that changes
          * remainingLength, the later seeds and the bytes.  The contract is the Java original
-         * (DESIGN.md section 2); frozen by tests/golden `d23_backoff`. */
-        if (low_end > low_start && i != 0 && i != tables - 1 && ((tables - i) & 1) == 0)
+         * (DESIGN.md section 2); frozen by tests/golden `d23_backoff`.
+         * PARITY UNPINNED at this statement: nothing runnable decides between the two readings.
+         * Building with -DORC_D23_SWIFT_TEXT=1 (oracle/Makefile: libbz2oracle_d23swift.so) gives the
+         * Swift-text reading, whose stream for the same input is frozen as `d23_backoff_swift_text`:
+         * a later decision on the contract is a one-line flip with a known expected stream. */
+        if (low_end > low_start && i != 0 && i != tables - 1 && ((tables - i) & 1) == 0) {
+#if ORC_D23_SWIFT_TEXT
+            low_end--;
+            actual -= freq[low_end];
+#else
             actual -= freq[low_end--];
+#endif
+        }
         for (int j = 0; j < alpha; j++)
             if (j < low_start || j > low_end) lengths[i][j] = 15;
         remaining -= actual;

@@ -245,6 +245,29 @@ def compress(data, level=9, threads=1, tie_rule=0):
     return out[:n].tobytes(), nb.value
 
 
+_lib_d23 = None
+
+
+def compress_d23_swift_text(data, level=9):
+    """The whole-stream oracle built with -DORC_D23_SWIFT_TEXT=1 (the Swift text's reading of the seed
+    back-off, D23).  Only tests/test_oracle.py and tests/golden/make_golden.py use it."""
+    global _lib_d23
+    if _lib_d23 is None:
+        so = os.path.join(_HERE, "libbz2oracle_d23swift.so")
+        if not os.path.exists(so):
+            subprocess.check_call(["make", "-C", _HERE, "-s"])
+        _lib_d23 = C.CDLL(so)
+        _lib_d23.orc_compress.restype = C.c_size_t
+        _lib_d23.orc_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                                          C.POINTER(C.c_int)]
+    a = _u8(data)
+    cap = lib().orc_compress_bound(a.size)
+    out = np.zeros(cap, dtype=np.uint8)
+    nb = C.c_int(0)
+    n = _lib_d23.orc_compress(_ptr(a), a.size, level, 0, _ptr(out), cap, C.byref(nb))
+    return out[:n].tobytes(), nb.value
+
+
 def split(data, level=9):
     a = _u8(data)
     mx = a.size // (level * 80000) + 16

@@ -65,6 +65,11 @@ def main():
             s, nb = orc.compress(data, level)
             ent["streams"][str(level)] = {"hex": s.hex(), "blocks": nb}
         out["small"][name] = ent
+    # the same input under the OTHER reading of D23 (the Swift text's), so that a later decision on the
+    # contract has its expected stream on file (oracle built with -DORC_D23_SWIFT_TEXT=1)
+    d23 = small_inputs()["d23_backoff"]
+    out["d23_backoff_swift_text"] = {"input": "small/d23_backoff", "streams": {
+        str(level): {"hex": orc.compress_d23_swift_text(d23, level)[0].hex()} for level in (1, 9)}}
     for kind, n, seed in large_inputs():
         data = corpus.segment(kind, n, seed)
         ent = {"kind": kind, "n": n, "seed": seed,

@@ -354,3 +354,23 @@ def test_tier2_array_length_decides_only_whether_the_reference_would_fail(orc):
             same += 1
         traps += t_tight
     assert traps >= 10 and same == 1200
+
+
+def test_d23_swift_text_reading_is_frozen_beside_the_chosen_one(orc):
+    """ADVICE r2: parity is unpinned at the seed back-off (D23).  The oracle follows the Java original;
+    the same oracle built with -DORC_D23_SWIFT_TEXT=1 gives the Swift text's reading.  Both streams
+    of the `d23_backoff` input are on file, so a later decision is a one-line flip with a known
+    expected stream; both decode."""
+    g = json.load(open(os.path.join(HERE, "golden", "golden.json")))
+    d = bytes.fromhex(g["small"]["d23_backoff"]["input_hex"])
+    for level in ("1", "9"):
+        java = orc.compress(d, int(level))[0]
+        swift = orc.compress_d23_swift_text(d, int(level))[0]
+        assert java.hex() == g["small"]["d23_backoff"]["streams"][level]["hex"]
+        assert swift.hex() == g["d23_backoff_swift_text"]["streams"][level]["hex"]
+        assert java != swift
+        assert bz2.decompress(java) == d and bz2.decompress(swift) == d
+    # everywhere the back-off branch is not taken the two builds agree
+    for name in ("banana", "abab", "random300"):
+        dd = bytes.fromhex(g["small"][name]["input_hex"])
+        assert orc.compress(dd, 9)[0] == orc.compress_d23_swift_text(dd, 9)[0]
