@@ -370,7 +370,7 @@ def test_d23_swift_text_reading_is_frozen_beside_the_chosen_one(orc):
         assert swift.hex() == g["d23_backoff_swift_text"]["streams"][level]["hex"]
         assert java != swift
         assert bz2.decompress(java) == d and bz2.decompress(swift) == d
-    # everywhere the back-off branch is not taken the two builds agree
-    for name in ("banana", "abab", "random300"):
+    # where the back-off branch cannot be taken (two tables: no middle table) the two builds agree
+    for name in ("banana", "abab", "hello"):
         dd = bytes.fromhex(g["small"][name]["input_hex"])
         assert orc.compress(dd, 9)[0] == orc.compress_d23_swift_text(dd, 9)[0]
