@@ -312,6 +312,8 @@ extern "C" int bz2hip_create(bz2hip_ctx **out, const bz2hip_opts *opts) {
         HIPCHK(hipEventCreateWithFlags(&c->ev_tie, hipEventDisableTiming));
         HIPCHK(hipStreamCreate(&c->stream_tie));
         HIPCHK(hipStreamCreate(&c->stream_copy));
+        for (int k = 0; k < RCTL_SLOTS; k++) HIPCHK(hipEventCreateWithFlags(&c->ev_ctl[k], hipEventDisableTiming));
+        HIPCHK(hipHostMalloc((void **)&c->h_ctl, RCTL_SLOTS * 64 * sizeof(u32), hipHostMallocDefault));
         // this device's copy of the static scratch (device `dev` is current)
         void *sp = nullptr;
         HIPCHK(hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch)));
@@ -324,6 +326,9 @@ extern "C" int bz2hip_create(bz2hip_ctx **out, const bz2hip_opts *opts) {
         if (c->ev_tie) (void)hipEventDestroy(c->ev_tie);
         if (c->stream_tie) (void)hipStreamDestroy(c->stream_tie);
         if (c->stream_copy) (void)hipStreamDestroy(c->stream_copy);
+        for (int k = 0; k < RCTL_SLOTS; k++)
+            if (c->ev_ctl[k]) (void)hipEventDestroy(c->ev_ctl[k]);
+        if (c->h_ctl) (void)hipHostFree(c->h_ctl);
         (void)hipStreamDestroy(c->stream);
         (void)hipStreamDestroy(c->stream_other);
         delete c;
@@ -385,6 +390,9 @@ extern "C" void bz2hip_destroy(bz2hip_ctx *c) {
     if (c->stream_tie) { (void)hipStreamSynchronize(c->stream_tie); (void)hipStreamDestroy(c->stream_tie); }
     if (c->stream_copy) { (void)hipStreamSynchronize(c->stream_copy); (void)hipStreamDestroy(c->stream_copy); }
     for (auto e : c->up_events) (void)hipEventDestroy(e);
+    for (int k = 0; k < RCTL_SLOTS; k++)
+        if (c->ev_ctl[k]) (void)hipEventDestroy(c->ev_ctl[k]);
+    if (c->h_ctl) (void)hipHostFree(c->h_ctl);
     (void)hipStreamDestroy(c->stream);
     (void)hipStreamDestroy(c->stream_other);
     delete c;

@@ -14,6 +14,8 @@
 #include <stdexcept>
 #include <cstdio>
 
+#define RCTL_SLOTS 4
+
 struct HipError : std::runtime_error {
     int code;
     HipError(int c, const std::string &m) : std::runtime_error(m), code(c) {}
@@ -175,6 +177,10 @@ struct bz2hip_ctx {
     u8 *scratch = nullptr;   // this device's address of the static scratch array (api.hip)
     hipEvent_t crc_done = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr; // S-sort || L-path inside a doubling round
+    // round control of the sort (k2_bwt.hip): page-locked slots the control words of the last rounds
+    // are copied to, and the events that say a slot is complete
+    u32 *h_ctl = nullptr;
+    hipEvent_t ev_ctl[RCTL_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t stream_tie = nullptr;  // replays of the reference's sorter for periodic blocks
     hipEvent_t ev_tie = nullptr;
     std::map<TieKey, u32> tie_cache;   // origin pointers of periodic blocks seen so far

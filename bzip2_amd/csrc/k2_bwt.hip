@@ -95,11 +95,27 @@ __global__ void k2_reset(const u32 *__restrict__ nArr, const u32 *__restrict__ p
 // exactly one class each -- the groups are the k-fold ties and can never split.  The block is then
 // finished now (its ties are flushed in list order) instead of doubling on to h >= n: "ab...",
 // zeros and the like take one or two rounds instead of log2(n).
+// Control words.  ctl[0..16) live for the whole sort: [4] any block finished as periodic, [5] / [6]
+// largest S- / L-list among those, [8] sum of the block lengths, [13..16) the tie replay's checks.
+// The words of ONE round sit in ctl[16 + 16 * (round & 1) ..): [0] any block goes on, [1] / [2] largest
+// S- / L-list, [3] / [4] elements in all L- / S-lists, [5] largest S + L of a block (bounds the next
+// round's lists: a block's lists only shrink, and nothing enters an L-list from an S-list).  A round
+// zeroes the other parity's words for its successor, so the loop needs no memset and the host can
+// read a round's words (copied in stream order) while later rounds are already queued.
+#define RC_ANY 0
+#define RC_MAXS 1
+#define RC_MAXL 2
+#define RC_SUML 3
+#define RC_SUMS 4
+#define RC_MAXSL 5
+#define CTL_WORDS 48
 __global__ __launch_bounds__(256) void k2_ctl(const u32 *__restrict__ nArr, u32 *mS, u32 *mL, u32 *mSn, u32 *mLn,
                                               u32 *hcur, u32 *huse, u32 *state, u32 *par, u32 *rounds,
-                                              u32 *gcount, const u8 *__restrict__ T, u32 S, u32 *ctl, u32 nb) {
+                                              u32 *gcount, const u8 *__restrict__ T, u32 S, u32 *ctl, u32 *rc,
+                                              u32 *rc_next, u32 nb) {
     const u32 b = blockIdx.x;
     if (b >= nb) return;
+    if (b == 0 && threadIdx.x < 8) rc_next[threadIdx.x] = 0;
     if (state[b] != ST_ACTIVE) return;
     __shared__ u32 sh[6];
     __shared__ u32 s_bad;
@@ -137,11 +153,12 @@ __global__ __launch_bounds__(256) void k2_ctl(const u32 *__restrict__ nArr, u32 
         huse[b] = h;
         hcur[b] = (h > (1u << 30)) ? h : 2 * h;
         rounds[b] += 1;
-        atomicOr(&ctl[0], 1u);
-        atomicMax(&ctl[1], s);
-        atomicMax(&ctl[2], l);
-        atomicAdd(&ctl[3], l);
-        atomicAdd(&ctl[7], s);
+        atomicOr(&rc[RC_ANY], 1u);
+        atomicMax(&rc[RC_MAXS], s);
+        atomicMax(&rc[RC_MAXL], l);
+        atomicAdd(&rc[RC_SUML], l);
+        atomicAdd(&rc[RC_SUMS], s);
+        atomicMax(&rc[RC_MAXSL], s + l);
     }
 }
 
@@ -1647,6 +1664,91 @@ __global__ __launch_bounds__(RT_THREADS, 3) void k2_ssort(const u64 *slA, const 
     PH_MARK(4);
 }
 
+// ------------------------------------------------------------------ small L-lists: the whole L-path in one kernel
+// Late rounds leave a few groups of more than GS elements: L-lists of some thousand elements that
+// still took 21 launches a round (rules 3, five radix passes of 3, re-rank 3), each a few
+// microseconds of work behind a launch that costs more.  When every L-list of the batch fits one
+// tile, one workgroup per block does the same work on its list in LDS: long-repeat rules (the tile
+// holds every group whole, so no flags cross tiles), a bitonic sort of the element words (grp, k2, i
+// = the order the five LSD passes produce), head flags, ranks, survivors to the S- / L-lists.
+__global__ __launch_bounds__(RT_THREADS) void k2_lsmall(u64 *__restrict__ keyA, u64 *slA, u64 *slB,
+                                                        const u32 *__restrict__ par,
+                                                        const u32 *__restrict__ mL,
+                                                        const u32 *__restrict__ state,
+                                                        u32 *__restrict__ rank, const u8 *__restrict__ T,
+                                                        u8 *__restrict__ bwt, const u32 *__restrict__ nArr,
+                                                        u32 *__restrict__ mSn, u32 *__restrict__ mLn,
+                                                        const u32 *__restrict__ huse,
+                                                        const u32 *__restrict__ runs,
+                                                        u32 *__restrict__ gcount, u32 S) {
+    const u32 b = blockIdx.x;
+    if (state[b] != ST_ACTIVE) return;
+    const u32 m = mL[b];
+    if (m == 0 || m > RTILE) return; // (the host takes this path only when every list fits)
+    __shared__ u64 buf[RTILE];
+    __shared__ int sm[16];
+    __shared__ u32 gfl[RTILE]; // flags of every group, at its head slot
+    __shared__ u32 s_runs[RUNS_STRIDE];
+    if (threadIdx.x < RUNS_STRIDE) s_runs[threadIdx.x] = runs ? runs[(size_t)b * RUNS_STRIDE + threadIdx.x] : 0u;
+    for (int q = threadIdx.x; q < RTILE; q += RT_THREADS) gfl[q] = 0;
+    __syncthreads();
+    const int w = wave_id(), lane = lane_id();
+    const u32 hcur = huse[b];
+    const u32 base = 0;
+    LAP_LOAD()
+    int lastHead = NOHEAD;
+#pragma unroll
+    for (int k = 0; k < RT_ITEMS; k++)
+        if (hm[k]) lastHead = w * 1024 + k * 64 + 63 - __clzll((unsigned long long)hm[k]);
+    if (lane == 0) sm[w] = lastHead;
+    __syncthreads();
+    int cO = NOHEAD;
+    for (int q = 0; q < w; q++)
+        if (sm[q] != NOHEAD) cO = sm[q];
+    int ohi[RT_ITEMS];
+    const u64 le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+#pragma unroll
+    for (int k = 0; k < RT_ITEMS; k++) {
+        const int rb = w * 1024 + k * 64;
+        const u64 mo = hm[k] & le;
+        ohi[k] = mo ? rb + 63 - __clzll((unsigned long long)mo) : cO;
+        if (hm[k]) cO = rb + 63 - __clzll((unsigned long long)hm[k]);
+        if (fl[k] && ohi[k] != NOHEAD) atomicOr(&gfl[ohi[k]], fl[k]); // (slot 0 is a head: ohi is never NOHEAD for j < m)
+    }
+    __syncthreads();
+    int N = 64;
+    while (N < (int)m) N <<= 1;
+#pragma unroll
+    for (int k = 0; k < RT_ITEMS; k++) {
+        const int idx = w * 1024 + k * 64 + lane;
+        if (idx < N) {
+            u64 e = ~0ull;
+            if ((u32)idx < m) {
+                e = ev[k];
+                const u32 gf = gfl[ohi[k]];
+                if (lap_qualifies(gf)) {
+                    const u32 slot = (u32)(idx - ohi[k]);
+                    const u32 code = (gf & GF_ASC) ? slot : (0xFFFFFu - slot);
+                    e = (e & ~(0xFFFFFull << KEY_SHIFT)) | ((u64)code << KEY_SHIFT);
+                }
+            }
+            buf[SZ(idx)] = e;
+        }
+    }
+    __syncthreads();
+    bitonic_sort_lds(buf, N);
+    int cls[16];
+    u32 ngrp[16], spos[16];
+    int nheads;
+    tile_classify<MODE_NORMAL, true>(buf, (int)m, 0, false, NOHEAD, NOHEAD, true, sm, cls, ngrp, spos, nheads);
+    u64 *sOut = (par[b] ? slA : slB) + (size_t)b * S; // the buffer the S-kernel of this round appends to
+    // the list was read whole before anything is written: its survivors go back to the front of it
+    tile_emit<MODE_NORMAL, true>(buf, (int)m, cls, ngrp, spos, rank + (size_t)b * S, T + (size_t)b * S,
+                                 bwt + (size_t)b * S, nArr[b], sOut, mSn + b, keyA + (size_t)b * S, 0, sm, gcount + b);
+    __syncthreads();
+    if (threadIdx.x == 0) mLn[b] = (u32)(sm[4] + sm[5] + sm[6] + sm[7]); // LKEEP counts per wave (tile_emit)
+}
+
 // ------------------------------------------------------------------ BWT bytes
 // bwt[rank[i]] = T[(i - 1) mod n] for every rotation: rank and T are streamed, the 1-byte stores
 // land in the block's n-byte BWT array, which stays in the XCD's L2 (XCD-aware mapping) until its
@@ -1820,7 +1922,7 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
     const auto t_begin = std::chrono::steady_clock::now();
     const u32 tiles = (maxn + RTILE - 1) / RTILE;
     const int cb = (nb + 255) / 256;
-    HIPCHK(hipMemsetAsync(B.ctl, 0, 16 * sizeof(u32), c->stream));
+    HIPCHK(hipMemsetAsync(B.ctl, 0, CTL_WORDS * sizeof(u32), c->stream));
     k2_reset<<<cb, 256, 0, c->stream>>>(B.n, B.present, B.mS, B.mL, B.mSn, B.mLn, B.hcur, B.huse,
                                         B.state, B.par, B.rounds, B.leftg, B.periodic, B.nheads, B.ctl, nb, c->r0bits);
     KCHECK();
@@ -1853,42 +1955,49 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
     }
     lrerank<MODE_ROUND0>(c, nb, maxn, B.n, ST_ACTIVE, B.keyB, B.keyA);
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
-    bool first = true;
+    // Round loop: k2_ctl of round r leaves its words in the control block (the round's own words are
+    // double-buffered, each round zeroes its successor's: no memset in the loop), one small copy brings
+    // them to a page-locked slot, and the host sizes the round's grids from them.  (Queueing round r
+    // from the words of round r - 1 without waiting was measured: the loop is bound by the host's
+    // launch rate in its tail, not by this wait, and the extra round of empty kernels at the end cost
+    // more than the waits it saved: 25.05 -> 25.45 ms.)
     u32 finS = 0, finL = 0;
     bool anyfin = false;
-    for (;;) {
-        HIPCHK(hipMemsetAsync(B.ctl, 0, 4 * sizeof(u32), c->stream));
-        HIPCHK(hipMemsetAsync(B.ctl + 7, 0, sizeof(u32), c->stream));
+    for (u32 r = 0;; r++) {
         k2_ctl<<<nb, 256, 0, c->stream>>>(B.n, B.mS, B.mL, B.mSn, B.mLn, B.hcur, B.huse, B.state, B.par,
-                                          B.rounds, B.nheads, B.T, B.S, B.ctl, nb);
+                                          B.rounds, B.nheads, B.T, B.S, B.ctl, B.ctl + 16 + 16 * (r & 1),
+                                          B.ctl + 16 + 16 * ((r + 1) & 1), nb);
         KCHECK();
-        u32 hc[9];
-        HIPCHK(hipMemcpyAsync(hc, B.ctl, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
+        u32 *hc = c->h_ctl;
+        HIPCHK(hipMemcpyAsync(hc, B.ctl, CTL_WORDS * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
-        if (first) {
+        const u32 *hr = hc + 16 + 16 * (r & 1);
+        if (r == 0) {
             if (c->profile) {
                 // pass 0 reads the block bytes (1 B) instead of 8-byte keys
                 c->prof_bytes[P_RADIX_SCATTER] += ((r0p - 1) * 16.0 + 9.0) * (double)hc[8];
                 c->prof_bytes[P_RADIX_HIST] += ((r0p - 1) * 8.0 + 1.0) * (double)hc[8];
             }
             c->st_sorted_elems += (u64)hc[8] * r0p;
-            first = false;
         }
         anyfin = hc[4] != 0;
         finS = hc[5];
         finL = hc[6];
-        if (!hc[0]) break;
-        const u32 maxS = hc[1], maxL = hc[2];
+        if (!hr[RC_ANY]) break;
+        const u32 maxS = hr[RC_MAXS], maxL = hr[RC_MAXL];
         if (c->debug >= 2)
-            fprintf(stderr, "[bz2hip] round: maxS=%u maxL=%u sumS=%u sumL=%u\n", maxS, maxL, hc[7], hc[3]);
-        c->st_sorted_elems += (u64)hc[3] * r0p;
-        c->st_s_elems += hc[7];
+            fprintf(stderr, "[bz2hip] round %u: maxS=%u maxL=%u sumS=%u sumL=%u\n", r, maxS, maxL, hr[RC_SUMS], hr[RC_SUML]);
+        const bool small_l = maxL && maxL <= RTILE; // every L-list fits one tile: one kernel does the L-path
+        c->st_s_elems += hr[RC_SUMS];
+        if (!small_l) c->st_sorted_elems += (u64)hr[RC_SUML] * r0p;
         if (c->profile) {
-            c->prof_bytes[P_RADIX_SCATTER] += r0p * 16.0 * (double)hc[3];
-            c->prof_bytes[P_RADIX_HIST] += r0p * 8.0 * (double)hc[3];
+            if (!small_l) {
+                c->prof_bytes[P_RADIX_SCATTER] += r0p * 16.0 * (double)hr[RC_SUML];
+                c->prof_bytes[P_RADIX_HIST] += r0p * 8.0 * (double)hr[RC_SUML];
+            }
             // keys: read E 8 + gather rank 4 + write E 8; ssort: read E 8 + write E 8 (LDS sort)
-            c->prof_bytes[P_BWT_KEYS] += 20.0 * ((double)hc[3] + (double)hc[7]);
-            c->prof_bytes[P_BWT_SSORT] += 16.0 * (double)hc[7];
+            c->prof_bytes[P_BWT_KEYS] += 20.0 * ((double)hr[RC_SUML] + (double)hr[RC_SUMS]);
+            c->prof_bytes[P_BWT_SSORT] += 16.0 * (double)hr[RC_SUMS];
         }
         {
             ProfScope ps(c, P_BWT_KEYS);
@@ -1900,7 +2009,7 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
         // The S-sort and the L-path of a round touch disjoint elements (both only append to the
         // next S-list through the atomic counter mSn): when both exist the L-path runs on the
         // other stream.
-        const bool fork = maxS && maxL;
+        const bool fork = maxS && maxL && !small_l;
         if (fork) {
             HIPCHK(hipEventRecord(c->ev_fork, c->stream));
             HIPCHK(hipStreamWaitEvent(c->stream_other, c->ev_fork, 0));
@@ -1914,7 +2023,12 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
             KCHECK();
             KCHECK();
         }
-        if (maxL) {
+        if (small_l) {
+            ProfScope ps(c, P_BWT_RERANK);
+            k2_lsmall<<<nb, RT_THREADS, 0, c->stream>>>(B.keyA, B.slA, B.slB, B.par, B.mL, B.state, B.rank, B.T, B.bwt,
+                                                        B.n, B.mSn, B.mLn, B.huse, B.runs, B.nheads, B.S);
+            KCHECK();
+        } else if (maxL) {
             if (fork) std::swap(c->stream, c->stream_other); // the drivers below launch on c->stream
             {
                 // long-repeat rules on the L-list (after k2_keys, before the sort)

@@ -1,6 +1,6 @@
 #!/bin/bash
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/r2/trace_${1:-x}
+OUT=$ROOT/gpurun_out/r3q/trace_${1:-x}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/t -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu --no-host --no-profile > $OUT/log 2>&1
