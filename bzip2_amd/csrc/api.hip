@@ -313,7 +313,8 @@ extern "C" int bz2hip_create(bz2hip_ctx **out, const bz2hip_opts *opts) {
         HIPCHK(hipStreamCreate(&c->stream_tie));
         HIPCHK(hipStreamCreate(&c->stream_copy));
         for (int k = 0; k < RCTL_SLOTS; k++) HIPCHK(hipEventCreateWithFlags(&c->ev_ctl[k], hipEventDisableTiming));
-        HIPCHK(hipHostMalloc((void **)&c->h_ctl, RCTL_SLOTS * 64 * sizeof(u32), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&c->h_ctl, (H_CTL_WORDS + H_PIN_WORDS) * sizeof(u32), hipHostMallocDefault));
+        c->h_pin = c->h_ctl + H_CTL_WORDS;
         // this device's copy of the static scratch (device `dev` is current)
         void *sp = nullptr;
         HIPCHK(hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch)));
@@ -469,7 +470,8 @@ static void compress_window_blocks(bz2hip_ctx *c, const u8 *d_win, const std::ve
         run_pack(c, nb, bs + 1, F.d_out, *F.bitpos, false, 0, F.out_cap, nullptr);
         u64 endbit;
         u32 crc_out;
-        run_frame(c, nb, F.d_out, F.level, !F.wrote_header, P.is_last, *F.stream_crc, &endbit, &crc_out);
+        u64 bst[4];
+        run_frame(c, nb, F.d_out, F.level, !F.wrote_header, P.is_last, *F.stream_crc, &endbit, &crc_out, bst);
         F.wrote_header = true;
         F.any_frame = true;
         *F.bitpos = endbit;
@@ -479,18 +481,12 @@ static void compress_window_blocks(bz2hip_ctx *c, const u8 *d_win, const std::ve
             F.crcs_out->resize(o + nb);
             HIPCHK(hipMemcpy(F.crcs_out->data() + o, B.crc, nb * sizeof(u32), hipMemcpyDeviceToHost));
         }
-        // stats
-        std::vector<u32> hr(nb), hp(nb), hn(nb);
-        HIPCHK(hipMemcpy(hr.data(), B.rounds, nb * sizeof(u32), hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(hp.data(), B.periodic, nb * sizeof(u32), hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(hn.data(), B.n, nb * sizeof(u32), hipMemcpyDeviceToHost));
-        for (int b = 0; b < nb; b++) {
-            c->st_blocks++;
-            c->st_rounds += hr[b];
-            c->st_rle_bytes += hn[b];
-            c->st_nr += (u64)hn[b] * hr[b];
-            if (hp[b] > 1) c->st_periodic++;
-        }
+        // stats: summed on the device by the framing kernel (one read-back instead of three arrays)
+        c->st_blocks += (u64)nb;
+        c->st_rounds += bst[0];
+        c->st_rle_bytes += bst[1];
+        c->st_nr += bst[2];
+        c->st_periodic += bst[3];
     };
     const int lane0 = c->active_lane;
     for (u32 b0 = 0, k = 0; b0 < usable; b0 += bsz, k++) {

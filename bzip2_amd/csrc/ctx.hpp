@@ -15,6 +15,8 @@
 #include <cstdio>
 
 #define RCTL_SLOTS 4
+#define H_CTL_WORDS 256     // page-locked control words (sort round loop, framing)
+#define H_PIN_WORDS 32768   // page-locked scratch for small read-backs (block starts, bit offsets)
 
 struct HipError : std::runtime_error {
     int code;
@@ -180,6 +182,7 @@ struct bz2hip_ctx {
     // round control of the sort (k2_bwt.hip): page-locked slots the control words of the last rounds
     // are copied to, and the events that say a slot is complete
     u32 *h_ctl = nullptr;
+    u32 *h_pin = nullptr;   // H_PIN_WORDS words behind h_ctl (one allocation, made by bz2hip_create)
     hipEvent_t ev_ctl[RCTL_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t stream_tie = nullptr;  // replays of the reference's sorter for periodic blocks
     hipEvent_t ev_tie = nullptr;
@@ -339,8 +342,9 @@ void run_huffman(bz2hip_ctx *c, int nb, u32 maxmtf);                   // k4_huf
 // writes blocks at absolute bit offsets into d_out (zeroed); first_bit = bit offset of block 0
 void run_pack(bz2hip_ctx *c, int nb, u32 maxmtf, u8 *d_out, u64 first_bit, bool per_block,
               size_t bits_stride, size_t out_cap_bytes, std::vector<u64> *h_nbits); // k4_huffman.hip
+// stats (optional, 4 words): sums over the batch of rounds, block lengths, length x rounds; periodic blocks
 void run_frame(bz2hip_ctx *c, int nb, u8 *d_out, int level, bool header, bool trailer, u32 crc_in,
-               u64 *end_bit, u32 *crc_out);                            // k4_huffman.hip
+               u64 *end_bit, u32 *crc_out, u64 *stats = nullptr);                            // k4_huffman.hip
 // K1 (k1_rle1.hip)
 void k1_init_tables(bz2hip_ctx *c);
 void run_scan(bz2hip_ctx *c, const u8 *d_in, u32 n, u32 *d_rs, u32 *d_P, u32 *d_agg1, u32 *d_agg2);

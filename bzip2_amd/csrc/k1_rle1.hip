@@ -821,6 +821,17 @@ u32 run_chain(bz2hip_ctx *c, const u8 *d_in, u32 n, int level, const u32 *d_rs, 
         KCHECK();
     }
     u32 cnt = 0;
+    if ((size_t)max_blocks + 2 <= H_PIN_WORDS) {
+        // one round trip: the count and every possible start go to page-locked scratch together
+        // (a few KB; the second, dependent read-back cost more than the bytes)
+        u32 *hp = c->h_pin;
+        HIPCHK(hipMemcpyAsync(hp, B.ctl + 9, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(hp + 1, d_starts, sizeof(u32) * ((size_t)max_blocks + 1), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        cnt = hp[0];
+        h_starts.assign(hp + 1, hp + 1 + cnt + 1);
+        return cnt;
+    }
     HIPCHK(hipMemcpyAsync(&cnt, B.ctl + 9, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     h_starts.resize(cnt + 1);

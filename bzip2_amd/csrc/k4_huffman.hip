@@ -661,10 +661,36 @@ __global__ __launch_bounds__(256) void k7_pack_p3(
 
 // ------------------------------------------------------------------ stream header / trailer
 // S/BZip2OutputStream.swift:139,154-157,181-184.  ctl_out[0..1] = end bit (lo, hi), [2] = crc
+// One wave.  Lane 0 frames the stream; all lanes add up the batch's statistics (what the host used to
+// fetch as three arrays): ctl_out[4..12) = sum of rounds, of block lengths, of length x rounds (u64
+// each) and the number of periodic blocks.
 __global__ void k8_frame(const u32 *__restrict__ crc, const u64 *__restrict__ bitoff, u32 nb,
                          u32 *__restrict__ out, int level, int write_header, int write_trailer,
-                         u32 crc_in, u32 *__restrict__ ctl_out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+                         u32 crc_in, u32 *__restrict__ ctl_out, const u32 *__restrict__ rounds,
+                         const u32 *__restrict__ periodic, const u32 *__restrict__ nArr) {
+    if (blockIdx.x != 0) return;
+    {
+        __shared__ unsigned long long acc[4];
+        if (threadIdx.x < 4) acc[threadIdx.x] = 0;
+        __syncthreads();
+        unsigned long long sr = 0, sn = 0, snr = 0, sp = 0;
+        for (u32 b = threadIdx.x; b < nb; b += blockDim.x) {
+            sr += rounds[b];
+            sn += nArr[b];
+            snr += (unsigned long long)nArr[b] * rounds[b];
+            sp += periodic[b] > 1;
+        }
+        atomicAdd(&acc[0], sr);
+        atomicAdd(&acc[1], sn);
+        atomicAdd(&acc[2], snr);
+        atomicAdd(&acc[3], sp);
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            ctl_out[4 + 2 * threadIdx.x] = (u32)(acc[threadIdx.x] & 0xffffffffu);
+            ctl_out[5 + 2 * threadIdx.x] = (u32)(acc[threadIdx.x] >> 32);
+        }
+    }
+    if (threadIdx.x != 0) return;
     if (write_header) {
         put_bits(out, 0, 16, 0x425a);
         put_bits(out, 16, 8, 0x68);
@@ -786,9 +812,13 @@ void run_pack(bz2hip_ctx *c, int nb, u32 maxmtf, u8 *d_out, u64 first_bit, bool 
                                             (u64)bits_stride * 8);
         KCHECK();
         // exact size check before a single bit is written
-        std::vector<u64> hb(2 * (nb + 1));
-        HIPCHK(hipMemcpyAsync(hb.data(), B.bitoff, sizeof(u64) * 2 * (nb + 1), hipMemcpyDeviceToHost,
-                              c->stream));
+        std::vector<u64> hbv;
+        u64 *hb = (u64 *)c->h_pin; // page-locked when it fits (it does up to 8191 blocks a batch)
+        if ((size_t)4 * (nb + 1) > H_PIN_WORDS) {
+            hbv.resize(2 * (nb + 1));
+            hb = hbv.data();
+        }
+        HIPCHK(hipMemcpyAsync(hb, B.bitoff, sizeof(u64) * 2 * (nb + 1), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         if (per_block) {
             for (int b = 0; b < nb; b++)
@@ -799,7 +829,7 @@ void run_pack(bz2hip_ctx *c, int nb, u32 maxmtf, u8 *d_out, u64 first_bit, bool 
             if ((hb[nb] + 80 + 7) / 8 + 8 > out_cap_bytes)
                 throw HipError(BZ2HIP_E_CAP, "output buffer too small");
         }
-        if (h_nbits) h_nbits->assign(hb.begin() + nb + 1, hb.begin() + nb + 1 + nb);
+        if (h_nbits) h_nbits->assign(hb + nb + 1, hb + nb + 1 + nb);
         k4_write_header<<<nb, 256, 0, c->stream>>>(B.nsel, B.ntables, B.alpha, B.present, B.crc,
                                                    B.orig, B.selpos, B.hlen, B.hdrbits, B.tblbits,
                                                    B.bitoff, (u32 *)d_out);
@@ -820,15 +850,17 @@ void run_pack(bz2hip_ctx *c, int nb, u32 maxmtf, u8 *d_out, u64 first_bit, bool 
 }
 
 void run_frame(bz2hip_ctx *c, int nb, u8 *d_out, int level, bool header, bool trailer, u32 crc_in,
-               u64 *end_bit, u32 *crc_out) {
+               u64 *end_bit, u32 *crc_out, u64 *stats) {
     Batch &B = c->batch;
     ProfScope ps(c, P_FINAL);
     k8_frame<<<1, 64, 0, c->stream>>>(B.crc, B.bitoff, nb, (u32 *)d_out, level, header ? 1 : 0,
-                                      trailer ? 1 : 0, crc_in, B.ctl + 4);
+                                      trailer ? 1 : 0, crc_in, B.ctl + 48, B.rounds, B.periodic, B.n);
     KCHECK();
-    u32 h[3];
-    HIPCHK(hipMemcpyAsync(h, B.ctl + 4, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    u32 *h = c->h_ctl + 128; // page-locked (the first 64 words belong to the sort's round loop)
+    HIPCHK(hipMemcpyAsync(h, B.ctl + 48, 12 * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     *end_bit = ((u64)h[1] << 32) | h[0];
     *crc_out = h[2];
+    if (stats)
+        for (int k = 0; k < 4; k++) stats[k] = ((u64)h[5 + 2 * k] << 32) | h[4 + 2 * k];
 }
