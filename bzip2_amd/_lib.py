@@ -355,10 +355,13 @@ class Context:
         self._chk(self.L.bz2hip_stream_finish(self.h))
 
     def stream_read(self, cap=1 << 20):
-        out = np.empty(cap, dtype=np.uint8)
+        # one landing buffer per context, reused: a fresh array per call costs its page faults again
+        buf = getattr(self, "_rbuf", None)
+        if buf is None or buf.size < cap:
+            buf = self._rbuf = np.empty(cap, dtype=np.uint8)
         n = C.c_size_t(0)
-        self._chk(self.L.bz2hip_stream_read(self.h, _p(out), cap, C.byref(n)))
-        return out[: n.value].tobytes()
+        self._chk(self.L.bz2hip_stream_read(self.h, _p(buf), cap, C.byref(n)))
+        return buf[: n.value].tobytes()
 
     def stream_pending(self):
         return self.L.bz2hip_stream_pending(self.h)

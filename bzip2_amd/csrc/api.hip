@@ -303,6 +303,7 @@ extern "C" int bz2hip_create(bz2hip_ctx **out, const bz2hip_opts *opts) {
     c->stream_chunk = (size_t)std::max(1, env_int("BZ2HIP_STREAM_CHUNK_MIB", (int)(STREAM_CHUNK >> 20))) << 20;
     c->stream_sync = env_int("BZ2HIP_STREAM_SYNC", 0) != 0;
     c->stream_least = (size_t)std::max(0, env_int("BZ2HIP_STREAM_LEAST_MIB", 0)) << 20;
+    c->stream_first = (size_t)std::max(1, env_int("BZ2HIP_STREAM_FIRST_MIB", 8)) << 20;
     if (int m = env_int("BZ2HIP_DEC_PASS_MIB", 0)) c->dec_pass_bytes = (u64)std::max(1, m) << 20;
     try {
         k1_init_tables(c);
@@ -370,8 +371,11 @@ extern "C" void bz2hip_destroy(bz2hip_ctx *c) {
     (void)hipSetDevice(c->device);
     for (int k = 0; k < 2; k++)
         if (c->sw.pin[k]) (void)hipHostFree(c->sw.pin[k]);
-    if (c->sw.d_in) (void)hipFree(c->sw.d_in);
-    if (c->sw.pin_out) (void)hipHostFree(c->sw.pin_out);
+    for (int k = 0; k < 2; k++) {
+        if (c->sw.d_buf[k]) (void)hipFree(c->sw.d_buf[k]);
+        if (c->sw.pin_out[k]) (void)hipHostFree(c->sw.pin_out[k]);
+        if (c->sw.ev_up[k]) (void)hipEventDestroy(c->sw.ev_up[k]);
+    }
     if (c->d_shift) (void)hipFree(c->d_shift);
     if (c->dec_region) (void)hipFree(c->dec_region);
     (void)hipStreamSynchronize(c->stream);
@@ -1226,6 +1230,10 @@ extern "C" int bz2hip_stream_begin(bz2hip_ctx *c, int level) {
     c->sw.fill = 0;
     c->sw.carry = 0;
     c->sw.err = 0;
+    c->sw.first_job = true;
+    c->sw.oq.clear();
+    c->sw.oq_bytes = 0;
+    c->sw.out_busy[0] = c->sw.out_busy[1] = false;
     c->s_level = level;
     c->s_open = true;
     c->s_finished = false;
@@ -1303,17 +1311,7 @@ static void stream_job(bz2hip_ctx *c, const bz2hip_ctx::StreamWorker::Job &job) 
     const auto t_job = std::chrono::steady_clock::now();
     const size_t n = W.carry + job.n;
     const size_t bound = bz2hip_compress_bound(n) + 16;
-    if (W.d_in_cap < n) {
-        // the device input buffer: sized for the largest hand-over plus a carried block; grown
-        // (keeping the carried bytes) only if a block of long runs carries more than that
-        const size_t want = std::max(n + (n >> 2), W.pin_cap + (size_t)c->s_level * 400000u);
-        u8 *nin = nullptr;
-        HIPCHK(hipMalloc((void **)&nin, want + 64));
-        if (W.carry) HIPCHK(hipMemcpy(nin, W.d_in, W.carry, hipMemcpyDeviceToDevice));
-        if (W.d_in) (void)hipFree(W.d_in);
-        W.d_in = nin;
-        W.d_in_cap = want;
-    }
+    if (W.carry > W.gap) throw HipError(BZ2HIP_E_HIP, "internal: carried bytes exceed the gap in front of the stream buffer");
     {
         // size the output staging and the batch workspace for the largest job this stream can hand
         // over, once, instead of growing them job by job (a few ms of hipFree / hipMalloc each time)
@@ -1324,45 +1322,76 @@ static void stream_job(bz2hip_ctx *c, const bz2hip_ctx::StreamWorker::Job &job) 
         if (!c->fixed_ws) ensure_batch(c, c->s_level, est);
     }
     const auto t_a = std::chrono::steady_clock::now();
-    if (job.n) HIPCHK(hipMemcpyAsync(W.d_in + W.carry, W.pin[job.buf], job.n, hipMemcpyHostToDevice, c->stream));
+    // the job's input: [carried bytes | the chunk], both already in HBM (the caller uploaded the
+    // chunk piece by piece while it filled it; the job before this one left the carried bytes)
+    // (a stream that is finished before anything was written has no buffers yet: n == 0 then)
+    const u8 *d_input = W.d_buf[job.buf] ? W.d_buf[job.buf] + W.gap - W.carry : nullptr;
+    if (n && !d_input) throw HipError(BZ2HIP_E_HIP, "internal: stream job without a device buffer");
+    if (W.ev_up[job.buf]) HIPCHK(hipStreamWaitEvent(c->stream, W.ev_up[job.buf], 0));
     const size_t zlen = bound & ~(size_t)3;
     HIPCHK(hipMemsetAsync(c->h_out, 0, zlen, c->stream));
     u64 bitpos = (u64)c->s_bitcnt;
     u32 scrc = c->s_stream_crc;
-    const size_t used = compress_core(c, W.d_in, n, c->s_level, c->h_out, zlen, &bitpos, &scrc, false, job.final);
+    const size_t used = compress_core(c, d_input, n, c->s_level, c->h_out, zlen, &bitpos, &scrc, false, job.final);
     c->s_stream_crc = scrc;
     const auto t_b = std::chrono::steady_clock::now();
     if (job.final || used > 0) {
-        // download into a page-locked buffer kept by the stream (a fresh pageable vector of this
-        // size costs more in page faults than the transfer takes)
+        // download into a page-locked landing buffer kept by the stream; bz2hip_stream_read takes the
+        // bytes from there (a copy into a heap queue cost as much again as the transfer)
         const size_t tlen = (size_t)((bitpos + 7) / 8);
         if (W.pin_out_cap < tlen + 8) {
-            if (W.pin_out) (void)hipHostFree(W.pin_out);
-            W.pin_out = nullptr;
+            {
+                // both buffers go: what they still hold moves to the heap queue first
+                std::lock_guard<std::mutex> lk(W.mu);
+                for (const auto &sg : W.oq) c->s_out.insert(c->s_out.end(), W.pin_out[sg.buf] + sg.off, W.pin_out[sg.buf] + sg.off + sg.len);
+                W.oq.clear();
+                W.oq_bytes = 0;
+                W.out_busy[0] = W.out_busy[1] = false;
+            }
+            for (int k = 0; k < 2; k++) {
+                if (W.pin_out[k]) (void)hipHostFree(W.pin_out[k]);
+                W.pin_out[k] = nullptr;
+            }
             W.pin_out_cap = 0;
-            HIPCHK(hipHostMalloc((void **)&W.pin_out, c->h_out_cap + 64, hipHostMallocDefault));
+            for (int k = 0; k < 2; k++) HIPCHK(hipHostMalloc((void **)&W.pin_out[k], c->h_out_cap + 64, hipHostMallocDefault));
             W.pin_out_cap = c->h_out_cap + 64;
         }
-        u8 *tmp = W.pin_out;
+        int ob;
         {
-            // the output queue grows once to the size of a job's output instead of doubling its way
-            // there (each doubling is a copy and a fresh set of page faults)
             std::lock_guard<std::mutex> lk(W.mu);
-            if (c->s_out.capacity() < tlen) c->s_out.reserve(c->s_out.size() + c->h_out_cap / 2);
+            if (W.out_busy[0] && W.out_busy[1]) {
+                // the reader is behind: the older buffer's unread bytes go to the heap queue
+                const int old = W.oq.front().buf;
+                while (!W.oq.empty() && W.oq.front().buf == old) {
+                    const auto sg = W.oq.front();
+                    c->s_out.insert(c->s_out.end(), W.pin_out[old] + sg.off, W.pin_out[old] + sg.off + sg.len);
+                    W.oq_bytes -= sg.len;
+                    W.oq.pop_front();
+                }
+                W.out_busy[old] = false;
+            }
+            ob = W.out_busy[0] ? 1 : 0;
+            W.out_busy[ob] = true;
         }
+        u8 *tmp = W.pin_out[ob];
         if (tlen) HIPCHK(hipMemcpy(tmp, c->h_out, tlen, hipMemcpyDeviceToHost));
         if (c->s_bitcnt > 0 && tlen) tmp[0] |= (u8)c->s_bitbuf;
         const size_t full = job.final ? tlen : (size_t)(bitpos / 8);
-        {
-            std::lock_guard<std::mutex> lk(W.mu);
-            c->s_out.insert(c->s_out.end(), tmp, tmp + full);
-        }
         if (!job.final) {
             c->s_bitcnt = (int)(bitpos & 7);
             c->s_bitbuf = c->s_bitcnt ? tmp[full] : 0;
         } else {
             c->s_bitcnt = 0;
             c->s_bitbuf = 0;
+        }
+        {
+            std::lock_guard<std::mutex> lk(W.mu);
+            if (full) {
+                W.oq.push_back({ob, 0, full});
+                W.oq_bytes += full;
+            } else {
+                W.out_busy[ob] = false;
+            }
         }
     }
     if (c->debug)
@@ -1371,17 +1400,15 @@ static void stream_job(bz2hip_ctx *c, const bz2hip_ctx::StreamWorker::Job &job) 
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_job).count(),
                 std::chrono::duration<double, std::milli>(t_a - t_job).count(),
                 std::chrono::duration<double, std::milli>(t_b - t_a).count());
-    const size_t rest = n - used;
-    if (rest && used) {
-        if (used >= rest) {
-            HIPCHK(hipMemcpyAsync(W.d_in, W.d_in + used, rest, hipMemcpyDeviceToDevice, c->stream));
-        } else { // the ranges overlap: through the output buffer (bound >= n > rest)
-            HIPCHK(hipMemcpyAsync(c->h_out, W.d_in + used, rest, hipMemcpyDeviceToDevice, c->stream));
-            HIPCHK(hipMemcpyAsync(W.d_in, c->h_out, rest, hipMemcpyDeviceToDevice, c->stream));
-        }
+    // the bytes of the incomplete last block: into the gap in front of the other buffer's data, where
+    // the next job (the buffers alternate) expects them
+    const size_t rest = job.final ? 0 : n - used;
+    if (rest > W.gap) throw HipError(BZ2HIP_E_HIP, "internal: an incomplete block holds more input than the gap in front of the stream buffer");
+    if (rest) {
+        HIPCHK(hipMemcpyAsync(W.d_buf[job.buf ^ 1] + W.gap - rest, d_input + used, rest, hipMemcpyDeviceToDevice, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
     }
-    W.carry = job.final ? 0 : rest;
+    W.carry = rest;
 }
 
 static void stream_worker(bz2hip_ctx *c) {
@@ -1438,6 +1465,9 @@ static void stream_submit(bz2hip_ctx *c, bool final) {
         W.running = true;
     }
     W.busy[W.cur] = true;
+    W.first_job = false;
+    // every piece of this buffer has been queued on the copy stream: the job waits for this event
+    if (W.ev_up[W.cur]) (void)hipEventRecord(W.ev_up[W.cur], c->stream_copy);
     W.q.push_back({W.cur, W.fill, final});
     W.active++;
     W.cv.notify_all();
@@ -1461,7 +1491,26 @@ static int stream_write_async(bz2hip_ctx *c, const uint8_t *p, size_t n) {
     // as the worker is idle and half a chunk has gathered -- so the first batch starts early and
     // later ones are as large as the GPU's pace allows (large batches compress faster).
     const size_t cap = 2 * c->stream_chunk, piece = (size_t)4 << 20;
-    const size_t least = c->stream_least ? std::min(c->stream_least, cap) : c->stream_chunk / 2;
+    // the first hand-over of a stream is small (the GPU starts while the caller is still writing),
+    // later ones as large as the GPU's pace allows
+    const size_t least_later = c->stream_least ? std::min(c->stream_least, cap) : c->stream_chunk / 2;
+    const size_t least = W.first_job ? std::min(least_later, c->stream_first) : least_later;
+    // device buffers behind a gap that holds whatever an incomplete block can carry over
+    const size_t gap = ((size_t)c->s_level * 100000u * 52u + 65536u + 255u) & ~(size_t)255;
+    if (hipSetDevice(c->device) != hipSuccess) return fail(c, BZ2HIP_E_HIP, "hipSetDevice failed");
+    if (W.pin_cap == cap && (W.gap < gap || W.d_buf_cap < cap)) {
+        // (no job is in flight and nothing is buffered: a stream of a higher level than the buffers were made for)
+        for (int k = 0; k < 2; k++) {
+            if (W.d_buf[k]) (void)hipFree(W.d_buf[k]);
+            W.d_buf[k] = nullptr;
+        }
+        W.d_buf_cap = 0;
+        W.pin_cap = 0; // sized again below
+        for (int k = 0; k < 2; k++) {
+            if (W.pin[k]) (void)hipHostFree(W.pin[k]);
+            W.pin[k] = nullptr;
+        }
+    }
     if (W.pin_cap != cap) {
         // (no job is in flight here: the buffers are only sized between streams or at the first write)
         if (hipSetDevice(c->device) != hipSuccess) return fail(c, BZ2HIP_E_HIP, "hipSetDevice failed");
@@ -1480,11 +1529,40 @@ static int stream_write_async(bz2hip_ctx *c, const uint8_t *p, size_t n) {
                 c->s_async = false;
                 return STREAM_GO_SYNC; // the caller goes on with the synchronous path
             }
+        bool dev_ok = true;
+        for (int k = 0; k < 2; k++) {
+            if (W.d_buf[k]) (void)hipFree(W.d_buf[k]);
+            W.d_buf[k] = nullptr;
+            if (!W.ev_up[k] && hipEventCreateWithFlags(&W.ev_up[k], hipEventDisableTiming) != hipSuccess) dev_ok = false;
+        }
+        W.d_buf_cap = 0;
+        for (int k = 0; k < 2 && dev_ok; k++)
+            if (hipMalloc((void **)&W.d_buf[k], gap + cap + 64) != hipSuccess) dev_ok = false;
+        if (!dev_ok) {
+            // no device memory for the stream buffers: this stream compresses inside write / finish
+            (void)hipGetLastError();
+            for (int k = 0; k < 2; k++) {
+                if (W.d_buf[k]) (void)hipFree(W.d_buf[k]);
+                if (W.pin[k]) (void)hipHostFree(W.pin[k]);
+                W.d_buf[k] = nullptr;
+                W.pin[k] = nullptr;
+            }
+            c->s_async = false;
+            return STREAM_GO_SYNC;
+        }
+        W.d_buf_cap = cap;
+        W.gap = gap;
         W.pin_cap = cap;
     }
     while (n) {
         const size_t k = std::min(std::min(W.pin_cap - W.fill, n), piece);
         memcpy(W.pin[W.cur] + W.fill, p, k);
+        // up it goes at once: by the time the buffer is handed over its bytes are in HBM
+        if (hipMemcpyAsync(W.d_buf[W.cur] + W.gap + W.fill, W.pin[W.cur] + W.fill, k, hipMemcpyHostToDevice,
+                           c->stream_copy) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(c, BZ2HIP_E_HIP, "upload of a stream chunk failed");
+        }
         W.fill += k;
         p += k;
         n -= k;
@@ -1545,7 +1623,8 @@ extern "C" int bz2hip_stream_finish(bz2hip_ctx *c) {
 
 extern "C" int bz2hip_stream_read(bz2hip_ctx *c, uint8_t *out, size_t cap, size_t *produced) {
     if (!c || !produced) return BZ2HIP_E_PARAM;
-    std::lock_guard<std::mutex> lk(c->sw.mu);
+    auto &W = c->sw;
+    std::lock_guard<std::mutex> lk(W.mu);
     size_t avail = c->s_out.size() - c->s_out_pos;
     size_t k = std::min(avail, cap);
     if (k) memcpy(out, c->s_out.data() + c->s_out_pos, k);
@@ -1554,6 +1633,23 @@ extern "C" int bz2hip_stream_read(bz2hip_ctx *c, uint8_t *out, size_t cap, size_
         c->s_out.clear();
         c->s_out_pos = 0;
     }
+    // then the jobs' landing buffers, in stream order
+    while (k < cap && c->s_out_pos == c->s_out.size() && !W.oq.empty()) {
+        auto &sg = W.oq.front();
+        const size_t m = std::min(sg.len, cap - k);
+        memcpy(out + k, W.pin_out[sg.buf] + sg.off, m);
+        k += m;
+        sg.off += m;
+        sg.len -= m;
+        W.oq_bytes -= m;
+        if (sg.len == 0) {
+            const int b = sg.buf;
+            W.oq.pop_front();
+            bool more = false;
+            for (const auto &o : W.oq) more = more || o.buf == b;
+            if (!more) W.out_busy[b] = false;
+        }
+    }
     *produced = k;
     return BZ2HIP_OK;
 }
@@ -1561,7 +1657,7 @@ extern "C" int bz2hip_stream_read(bz2hip_ctx *c, uint8_t *out, size_t cap, size_
 extern "C" size_t bz2hip_stream_pending(const bz2hip_ctx *c) {
     if (!c) return 0;
     std::lock_guard<std::mutex> lk(const_cast<bz2hip_ctx *>(c)->sw.mu);
-    return c->s_out.size() - c->s_out_pos;
+    return c->s_out.size() - c->s_out_pos + c->sw.oq_bytes;
 }
 
 // ------------------------------------------------------------------ stage entry points

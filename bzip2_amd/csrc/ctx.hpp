@@ -169,6 +169,7 @@ struct bz2hip_ctx {
     u32 radix_bits = 8;      // BZ2HIP_RADIX_BITS: digit width of the LSD passes (8: 5 passes, 10: 4 passes)
     size_t stream_chunk = (size_t)64 << 20; // BZ2HIP_STREAM_CHUNK_MIB: streaming flush threshold per GPU
     size_t stream_least = 0;                // BZ2HIP_STREAM_LEAST_MIB: hand-over threshold while the worker is idle (0: half a chunk)
+    size_t stream_first = (size_t)8 << 20;  // BZ2HIP_STREAM_FIRST_MIB: hand-over threshold of a stream's first job
     bool stream_sync = false;               // BZ2HIP_STREAM_SYNC: compress inside bz2hip_stream_write (experiments)
     u64 dec_pass_bytes = 0xfffffff0ull;     // BZ2HIP_DEC_PASS_MIB (tests): decoded bytes written per pass (u32 offsets)
     // decoder workspace, kept between calls (one region, grown on demand)
@@ -273,11 +274,25 @@ struct bz2hip_ctx {
         size_t pin_cap = 0;
         int cur = 0;                   // caller: the buffer being filled, and its fill
         size_t fill = 0;
-        u8 *pin_out = nullptr;         // worker: page-locked landing buffer of a job's output
+        // worker: two page-locked landing buffers for the jobs' output.  A job's bytes are read by
+        // bz2hip_stream_read straight from its landing buffer (oq lists them in order); only when both
+        // buffers still hold unread bytes is the older one moved to the heap queue s_out.
+        u8 *pin_out[2] = {nullptr, nullptr};
         size_t pin_out_cap = 0;
-        u8 *d_in = nullptr;            // worker: device input buffer of the stream
-        size_t d_in_cap = 0;
-        size_t carry = 0;              // worker: bytes of an incomplete last block kept at the front of d_in
+        bool out_busy[2] = {false, false};
+        struct OutSeg { int buf; size_t off, len; };
+        std::deque<OutSeg> oq;         // after s_out in stream order
+        size_t oq_bytes = 0;
+        // device input buffers, one per page-locked chunk buffer: the caller uploads every piece it
+        // has copied into pin[k] to d_buf[k] + gap + offset at once (copy stream), so a job's input is
+        // in HBM when the job starts; the bytes of an incomplete last block are carried into the gap
+        // in front of the other buffer's data by the job that leaves them
+        u8 *d_buf[2] = {nullptr, nullptr};
+        size_t d_buf_cap = 0;          // bytes behind the gap
+        size_t gap = 0;                // >= the input an incomplete block can hold
+        hipEvent_t ev_up[2] = {nullptr, nullptr};
+        size_t carry = 0;              // worker: carried bytes in front of the next job's buffer
+        bool first_job = true;         // caller: nothing handed over yet in this stream
     } sw;
     bool s_async = false;
 
