@@ -303,7 +303,7 @@ extern "C" int bz2hip_create(bz2hip_ctx **out, const bz2hip_opts *opts) {
     c->stream_chunk = (size_t)std::max(1, env_int("BZ2HIP_STREAM_CHUNK_MIB", (int)(STREAM_CHUNK >> 20))) << 20;
     c->stream_sync = env_int("BZ2HIP_STREAM_SYNC", 0) != 0;
     c->stream_least = (size_t)std::max(0, env_int("BZ2HIP_STREAM_LEAST_MIB", 0)) << 20;
-    c->stream_first = (size_t)std::max(1, env_int("BZ2HIP_STREAM_FIRST_MIB", 8)) << 20;
+    c->stream_first = (size_t)std::max(1, env_int("BZ2HIP_STREAM_FIRST_MIB", 32)) << 20;
     if (int m = env_int("BZ2HIP_DEC_PASS_MIB", 0)) c->dec_pass_bytes = (u64)std::max(1, m) << 20;
     try {
         k1_init_tables(c);
@@ -1491,8 +1491,9 @@ static int stream_write_async(bz2hip_ctx *c, const uint8_t *p, size_t n) {
     // as the worker is idle and half a chunk has gathered -- so the first batch starts early and
     // later ones are as large as the GPU's pace allows (large batches compress faster).
     const size_t cap = 2 * c->stream_chunk, piece = (size_t)4 << 20;
-    // the first hand-over of a stream is small (the GPU starts while the caller is still writing),
-    // later ones as large as the GPU's pace allows
+    // the first hand-over of a stream has a threshold of its own (BZ2HIP_STREAM_FIRST_MIB; measured
+    // with a caller that writes at 20+ GB/s: 8 / 16 / 32 MiB give 37.4 / 37.5 / 35.9 ms per 256 MiB, so
+    // it defaults to the later ones' 32 MiB); later ones are as large as the GPU's pace allows
     const size_t least_later = c->stream_least ? std::min(c->stream_least, cap) : c->stream_chunk / 2;
     const size_t least = W.first_job ? std::min(least_later, c->stream_first) : least_later;
     // device buffers behind a gap that holds whatever an incomplete block can carry over

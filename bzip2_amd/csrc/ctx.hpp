@@ -169,7 +169,7 @@ struct bz2hip_ctx {
     u32 radix_bits = 8;      // BZ2HIP_RADIX_BITS: digit width of the LSD passes (8: 5 passes, 10: 4 passes)
     size_t stream_chunk = (size_t)64 << 20; // BZ2HIP_STREAM_CHUNK_MIB: streaming flush threshold per GPU
     size_t stream_least = 0;                // BZ2HIP_STREAM_LEAST_MIB: hand-over threshold while the worker is idle (0: half a chunk)
-    size_t stream_first = (size_t)8 << 20;  // BZ2HIP_STREAM_FIRST_MIB: hand-over threshold of a stream's first job
+    size_t stream_first = (size_t)32 << 20;  // BZ2HIP_STREAM_FIRST_MIB: hand-over threshold of a stream's first job
     bool stream_sync = false;               // BZ2HIP_STREAM_SYNC: compress inside bz2hip_stream_write (experiments)
     u64 dec_pass_bytes = 0xfffffff0ull;     // BZ2HIP_DEC_PASS_MIB (tests): decoded bytes written per pass (u32 offsets)
     // decoder workspace, kept between calls (one region, grown on demand)
