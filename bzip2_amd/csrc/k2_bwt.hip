@@ -27,6 +27,13 @@
 #define SC 3072          // S-tile nominal stride (window = SC + GS = 4096)
 #define KEY_SHIFT 20
 #define E_IMASK 0xFFFFFull
+// long repeats at a fixed distance (see "long repeats" below; the round-0 re-rank uses the regions too)
+#define VT 8192           // vote slots per block
+#define NCAND 2           // distances kept per block
+#define MAXRUNS 8         // regions kept per distance
+#define MINRUN 4096u      // shortest gap of V worth recording (also > tile, so a tile holds no whole gap)
+#define RUNS_STRIDE (4 + 4 * NCAND * MAXRUNS)
+#define VSLOT(d) (((d) * 2654435761u) >> 19)
 
 // XCD-aware launch: workgroups are dealt round-robin over the 8 XCDs by linear id, so block b
 // is handled only by ids congruent to b mod 8: its rank array / lists stay in one XCD's L2.
@@ -510,7 +517,8 @@ template <int MODE, bool SWZ = false>
 __device__ __forceinline__ void tile_classify(const u64 *buf, int cnt, u64 prevE, bool has_prev,
                                               int carryOld, int carryNew, bool end_head,
                                               int *sm /* 12 ints */, int (&cls)[16],
-                                              u32 (&ngrp)[16], u32 (&spos)[16], int &nheads) {
+                                              u32 (&ngrp)[16], u32 (&spos)[16], int &nheads,
+                                              int *gsz = nullptr /* [16]: size of the element's group if it lies inside the tile, else 0 */) {
     const int w = wave_id(), lane = lane_id();
     u64 nm[16], om[16];
     int lastOld = NOHEAD, lastNew = NOHEAD, firstNew = CROSS;
@@ -591,10 +599,14 @@ __device__ __forceinline__ void tile_classify(const u64 *buf, int cnt, u64 prevE
             sp = gb + (u32)(idx - ohi[k]);
             if (nhi[k] < 0 || next == CROSS) {
                 c = CLS_LKEEP;
+                if (gsz) gsz[k] = 0;
             } else {
                 int size = next - nhi[k];
                 c = (size == 1) ? CLS_SINGLE : (size <= GS ? CLS_SMALL : CLS_LKEEP);
+                if (gsz) gsz[k] = size;
             }
+        } else if (gsz) {
+            gsz[k] = 0;
         }
         cls[k] = c;
         ngrp[k] = g;
@@ -703,13 +715,77 @@ __device__ __forceinline__ void tile_emit(const u64 *buf, int cnt, const int (&c
     }
 }
 
+// ------------------------------------------------------------------ run rule in round 0
+// The run rule (below, "long repeats at a fixed distance") needs nothing a doubling round produces:
+// a group of the round-0 list -- equal first d0 symbols, members in index order -- whose members are
+// i0, i0 + p, i0 + 2p, ... inside ONE recorded region of distance p > d0 is ordered by T alone (every
+// pair (i, i + p) first differs at the region's end e, T[e - p] against T[e]).  Such a group is
+// finished in the re-rank of round 0: its members get their final ranks (head + slot, or the
+// reverse) and never enter a list, so the first doubling round -- the largest -- does not gather,
+// sort and re-rank them.  Only groups that lie inside one tile are taken (the flags of a group are
+// OR-ed at its head slot in LDS); a group that crosses a tile boundary takes the ordinary path, as
+// does anything that fails a check.  Phase 1 and phase 3 of the re-rank both apply it, so their
+// counts agree.
+#define GF_R0_RUN 16u
+#define GF_R0_ASC 2u
+#define GF_R0_DESC 4u
+#define GF_R0_BAD 8u
+__device__ __forceinline__ void round0_run_rule(const u64 *buf, int cnt, int (&cls)[16], u32 (&ngrp)[16],
+                                                const u32 (&spos)[16], const int (&gsz)[16], u8 *gflag /* [RTILE] */,
+                                                const u32 *s_runs, u32 d0) {
+    const int w = wave_id(), lane = lane_id();
+    const u32 nr = s_runs[0];
+    if (nr == 0) return; // (uniform over the workgroup: s_runs is shared)
+    for (int q = threadIdx.x; q < RTILE / 4; q += RT_THREADS) ((u32 *)gflag)[q] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int idx = w * 1024 + k * 64 + lane;
+        if ((cls[k] == CLS_SMALL || cls[k] == CLS_LKEEP) && gsz[k] > 1) {
+            const int slot = (int)(spos[k] - ngrp[k]);
+            if (slot >= 1) {
+                const u64 e = buf[idx], ep = buf[idx - 1];
+                const u32 i1 = (u32)(e & E_IMASK), i0 = (u32)(ep & E_IMASK);
+                const u32 d = i1 - i0;
+                u32 f = GF_R0_BAD;
+                if (i1 > i0 && d > d0) {
+                    u32 ok = 0;
+                    for (u32 r = 0; r < nr; r++) {
+                        const u32 *R = s_runs + 4 + 4 * r;
+                        if (R[0] == d && i0 >= R[1] && i1 <= R[2]) ok = R[3];
+                    }
+                    if (ok) f = GF_R0_RUN | ok;
+                }
+                if (slot >= 2 && i0 - (u32)(buf[idx - 2] & E_IMASK) != d) f |= GF_R0_BAD;
+                const int h = idx - slot;
+                atomicOr((u32 *)gflag + (h >> 2), f << ((h & 3) * 8));
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int idx = w * 1024 + k * 64 + lane;
+        if ((cls[k] == CLS_SMALL || cls[k] == CLS_LKEEP) && gsz[k] > 1) {
+            const int slot = (int)(spos[k] - ngrp[k]);
+            const u32 gf = gflag[idx - slot];
+            const u32 dir = gf & (GF_R0_ASC | GF_R0_DESC);
+            if ((gf & GF_R0_RUN) && !(gf & GF_R0_BAD) && (dir == GF_R0_ASC || dir == GF_R0_DESC)) {
+                cls[k] = CLS_SINGLE;
+                ngrp[k] += (dir == GF_R0_ASC) ? (u32)slot : (u32)(gsz[k] - 1 - slot);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ L-path re-rank
 // phase 1: per tile {last old head + 1, last new head + 1, LKEEP count}
 template <int MODE>
 __global__ __launch_bounds__(RT_THREADS) void k2_lrerank_p1(const u64 *__restrict__ key,
                                                             const u32 *__restrict__ cntArr,
                                                             const u32 *__restrict__ state, u32 want,
-                                                            u32 *__restrict__ tileagg, u32 S, u32 TPB, u32 gtiles, u32 gnb) {
+                                                            u32 *__restrict__ tileagg, u32 S, u32 TPB, u32 gtiles, u32 gnb,
+                                                            const u32 *__restrict__ huse, const u32 *__restrict__ runs) {
     XCD_MAP(gtiles, gnb)
     const u32 b = bz_b;
     if (state[b] != want) return;
@@ -718,6 +794,10 @@ __global__ __launch_bounds__(RT_THREADS) void k2_lrerank_p1(const u64 *__restric
     if (base >= m) return;
     __shared__ u64 buf[RTILE];
     __shared__ int sm[16];
+    __shared__ __attribute__((aligned(16))) u8 gflag[MODE == MODE_ROUND0 ? RTILE : 4];
+    __shared__ u32 s_runs[MODE == MODE_ROUND0 ? RUNS_STRIDE : 1];
+    if (MODE == MODE_ROUND0 && threadIdx.x < RUNS_STRIDE)
+        s_runs[threadIdx.x] = runs ? runs[(size_t)b * RUNS_STRIDE + threadIdx.x] : 0u;
     const u64 *kp = key + (size_t)b * S;
     const int cnt = (int)min((u32)RTILE, m - base);
     {
@@ -740,7 +820,10 @@ __global__ __launch_bounds__(RT_THREADS) void k2_lrerank_p1(const u64 *__restric
     u32 ngrp[16], spos[16];
     int nheads;
     // carries are irrelevant for the aggregates: use NOHEAD so that heads before the tile read < 0
-    tile_classify<MODE>(buf, cnt, prevE, has_prev, NOHEAD, NOHEAD, end_head, sm, cls, ngrp, spos, nheads);
+    int gsz[16];
+    tile_classify<MODE>(buf, cnt, prevE, has_prev, NOHEAD, NOHEAD, end_head, sm, cls, ngrp, spos, nheads,
+                        MODE == MODE_ROUND0 ? gsz : nullptr);
+    if (MODE == MODE_ROUND0) round0_run_rule(buf, cnt, cls, ngrp, spos, gsz, gflag, s_runs, huse[b]);
     // aggregates
     const int w = wave_id(), lane = lane_id();
     int lastOld = 0, lastNew = 0;
@@ -815,7 +898,7 @@ __global__ __launch_bounds__(RT_THREADS) void k2_lrerank_p3(
     const u32 *__restrict__ state, u32 want, const u32 *__restrict__ tileagg,
     u32 *__restrict__ rank, const u8 *__restrict__ T, u8 *__restrict__ bwt,
     const u32 *__restrict__ nArr, u32 *__restrict__ mSn, u32 *__restrict__ gcount, u32 S, u32 TPB,
-    u32 gtiles, u32 gnb, u32 nsw) {
+    u32 gtiles, u32 gnb, u32 nsw, const u32 *__restrict__ huse, const u32 *__restrict__ runs) {
     // round 0 writes the rank of every position, in sorted order: a block's rank array does not
     // stay in its XCD's L2 next to the streaming lists, so the pass is swept nsw times, each
     // sweep writing only the ranks that fall in one 1/nsw window of positions
@@ -829,6 +912,10 @@ __global__ __launch_bounds__(RT_THREADS) void k2_lrerank_p3(
     if (base >= m) return;
     __shared__ u64 buf[RTILE];
     __shared__ int sm[16];
+    __shared__ __attribute__((aligned(16))) u8 gflag[MODE == MODE_ROUND0 ? RTILE : 4];
+    __shared__ u32 s_runs[MODE == MODE_ROUND0 ? RUNS_STRIDE : 1];
+    if (MODE == MODE_ROUND0 && threadIdx.x < RUNS_STRIDE)
+        s_runs[threadIdx.x] = runs ? runs[(size_t)b * RUNS_STRIDE + threadIdx.x] : 0u;
     const u64 *kp = key + (size_t)b * S;
     const int cnt = (int)min((u32)RTILE, m - base);
     {
@@ -854,7 +941,10 @@ __global__ __launch_bounds__(RT_THREADS) void k2_lrerank_p3(
     int cls[16];
     u32 ngrp[16], spos[16];
     int nheads;
-    tile_classify<MODE>(buf, cnt, prevE, has_prev, carryOld, carryNew, end_head, sm, cls, ngrp, spos, nheads);
+    int gsz[16];
+    tile_classify<MODE>(buf, cnt, prevE, has_prev, carryOld, carryNew, end_head, sm, cls, ngrp, spos, nheads,
+                        MODE == MODE_ROUND0 ? gsz : nullptr);
+    if (MODE == MODE_ROUND0) round0_run_rule(buf, cnt, cls, ngrp, spos, gsz, gflag, s_runs, huse[b]);
     // S survivors go to the buffer the S-kernel of this round also appends to
     u64 *sOut = (par[b] ? slA : slB) + (size_t)b * S;
     const u32 nblk = nArr[b], win = (nblk + nsw - 1) / nsw;
@@ -964,12 +1054,6 @@ __device__ __forceinline__ void bitonic_sort_lds(u64 *buf, int N) {
 // i+p reads T[e].  The first S-round votes for the distances p seen between group neighbours,
 // k2_pick keeps the two most frequent per block, k2_viol/k2_runs list their long regions, and
 // k2_ssort then finishes any group whose index-ordered members are all such pairs (run rule).
-#define VT 8192           // vote slots per block
-#define NCAND 2           // distances kept per block
-#define MAXRUNS 8         // regions kept per distance
-#define MINRUN 4096u      // shortest gap of V worth recording (also > tile, so a tile holds no whole gap)
-#define RUNS_STRIDE (4 + 4 * NCAND * MAXRUNS)
-#define VSLOT(d) (((d) * 2654435761u) >> 19)
 
 // Votes of round 0: the sorted round-0 list (key << 20 | i, equal keys in index order) is sampled at
 // the first 64 slots of every fourth tile; neighbours with equal keys vote for their distance (one
@@ -1841,13 +1925,14 @@ void run_present(bz2hip_ctx *c, int nb, u32 maxn) {
 #define nbarg(nb, bit) ((c->plain_mask & (bit)) ? ((u32)(nb) | 0x80000000u) : (u32)(nb))
 
 // `from_T`: the first pass builds the round-0 keys from the block bytes instead of reading `a`
+// passes [first_pass, passes) of the sort; `a` is the input of pass `first_pass`, `bbuf` its output
 template <int DB, bool STG>
 static void radix_sort_db(bz2hip_ctx *c, int nb, u32 maxcnt, const u32 *cntArr, u64 *a, u64 *bbuf,
-                          int passes, bool from_T) {
+                          int passes, bool from_T, int first_pass) {
     Batch &B = c->batch;
     const u32 tiles = (maxcnt + RTILE - 1) / RTILE;
     u64 *kin = a, *kout = bbuf;
-    for (int p = 0; p < passes; p++) {
+    for (int p = first_pass; p < passes; p++) {
         int shift = KEY_SHIFT + DB * p;
         const bool ft = from_T && p == 0;
         {
@@ -1884,14 +1969,17 @@ static void radix_sort_db(bz2hip_ctx *c, int nb, u32 maxcnt, const u32 *cntArr, 
 // sorts the 40 key bits [59:20]: 5 passes of 8 bits or 4 of 10 (c->radix_bits); the sorted words end
 // in `bbuf` when the pass count is odd, in `a` when it is even
 static int radix_passes(const bz2hip_ctx *c) { return 40 / (int)c->radix_bits; }
+// round 0 sorts r0bits key bits only (BZ2HIP_R0BITS; the default 40 = the whole field)
+static int radix_passes0(const bz2hip_ctx *c) { return ((int)c->r0bits + (int)c->radix_bits - 1) / (int)c->radix_bits; }
 static void radix_sort5(bz2hip_ctx *c, int nb, u32 maxcnt, const u32 *cntArr, u64 *a, u64 *bbuf,
-                        bool from_T = false) {
+                        bool from_T = false, int passes = 0, int first_pass = 0) {
+    if (!passes) passes = radix_passes(c);
     if (c->radix_bits == 10) {
-        if (c->radix_stage) radix_sort_db<10, true>(c, nb, maxcnt, cntArr, a, bbuf, 4, from_T);
-        else radix_sort_db<10, false>(c, nb, maxcnt, cntArr, a, bbuf, 4, from_T);
+        if (c->radix_stage) radix_sort_db<10, true>(c, nb, maxcnt, cntArr, a, bbuf, passes, from_T, first_pass);
+        else radix_sort_db<10, false>(c, nb, maxcnt, cntArr, a, bbuf, passes, from_T, first_pass);
     } else {
-        if (c->radix_stage) radix_sort_db<8, true>(c, nb, maxcnt, cntArr, a, bbuf, 5, from_T);
-        else radix_sort_db<8, false>(c, nb, maxcnt, cntArr, a, bbuf, 5, from_T);
+        if (c->radix_stage) radix_sort_db<8, true>(c, nb, maxcnt, cntArr, a, bbuf, passes, from_T, first_pass);
+        else radix_sort_db<8, false>(c, nb, maxcnt, cntArr, a, bbuf, passes, from_T, first_pass);
     }
 }
 
@@ -1902,8 +1990,10 @@ static void lrerank(bz2hip_ctx *c, int nb, u32 maxcnt, const u32 *cntArr, u32 wa
     const u32 tiles = (maxcnt + RTILE - 1) / RTILE;
     dim3 grid(tiles, nb);
     ProfScope ps(c, P_BWT_RERANK);
+    const u32 *r0runs = (MODE == MODE_ROUND0 && c->r0_rule) ? B.runs : nullptr;
     k2_lrerank_p1<MODE><<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(sorted, cntArr, B.state, want,
-                                                                           B.tileagg, B.S, B.TPB, tiles, nbarg(nb, 4));
+                                                                           B.tileagg, B.S, B.TPB, tiles, nbarg(nb, 4),
+                                                                           B.huse, r0runs);
     KCHECK();
     k2_lrerank_p2<<<nb, 256, 0, c->stream>>>(cntArr, B.state, want, B.tileagg, B.mLn, B.leftg,
                                              MODE == MODE_FINAL ? 1 : 0, B.TPB);
@@ -1911,7 +2001,7 @@ static void lrerank(bz2hip_ctx *c, int nb, u32 maxcnt, const u32 *cntArr, u32 wa
     const u32 nsw = (MODE == MODE_ROUND0) ? c->r0_sweeps : 1u;
     k2_lrerank_p3<MODE><<<xcd_grid(tiles * nsw, nb), RT_THREADS, 0, c->stream>>>(
         sorted, lout, B.slA, B.slB, B.par, cntArr, B.state, want, B.tileagg, B.rank, B.T, B.bwt, B.n,
-        B.mSn, B.nheads, B.S, B.TPB, tiles, nbarg(nb, 4), nsw);
+        B.mSn, B.nheads, B.S, B.TPB, tiles, nbarg(nb, 4), nsw, B.huse, r0runs);
     KCHECK();
 }
 
@@ -1926,24 +2016,29 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
     k2_reset<<<cb, 256, 0, c->stream>>>(B.n, B.present, B.mS, B.mL, B.mSn, B.mLn, B.hcur, B.huse,
                                         B.state, B.par, B.rounds, B.leftg, B.periodic, B.nheads, B.ctl, nb, c->r0bits);
     KCHECK();
-    const int r0p = radix_passes(c); // r0bits = 40 key bits
+    const int r0p = radix_passes(c);   // passes over an L-list: the whole 40-bit field
+    const int r0p0 = radix_passes0(c); // passes of round 0: its r0bits key bits
     // The first pass reads the block bytes, so the keys are first written by its scatter.  The
     // sorted keys must end in keyB (the L-list is rebuilt into keyA): with an odd pass count the
     // passes go (T) -> keyB -> keyA -> ... -> keyB, so the "input" of pass 0 is nominally keyA.
-    if (r0p & 1) radix_sort5(c, nb, maxn, B.n, B.keyA, B.keyB, true);
-    else radix_sort5(c, nb, maxn, B.n, B.keyB, B.keyA, true);
-    // Repeat distances are voted for on the round-0 list, so that the run rule already applies in the
-    // first doubling round (the rules are exact whatever the votes: a poor candidate costs time,
-    // never correctness).  Voting again after the first round, on ties twice as deep, changed no
-    // family's round count and cost 0.3 ms (measured), so the regions are listed once.  The chain
-    // votes -> picks -> regions only reads the sorted list and T: it runs on the other stream beside
-    // the round-0 re-rank.
+    u64 *const A0 = (r0p0 & 1) ? B.keyA : B.keyB, *const B0 = (r0p0 & 1) ? B.keyB : B.keyA;
+    // all passes but the last
+    radix_sort5(c, nb, maxn, B.n, A0, B0, true, r0p0 - 1);
+    u64 *const part = ((r0p0 - 1) & 1) ? B0 : A0; // sorted by all key bits but the top digit
+    // Repeat distances are voted for BEFORE the last pass, on the list sorted by the low key bits:
+    // neighbours with equal (whole) keys are still neighbours there unless an element that differs
+    // in the top digit only sits between them, and the votes are a heuristic anyway (the rules are
+    // exact whatever the votes: a poor candidate costs time, never correctness).  The chain votes ->
+    // picks -> regions reads that list and T only: it runs on the other stream beside the last pass,
+    // and its regions are ready for the re-rank of round 0, which finishes the groups they order
+    // (round0_run_rule), and for every doubling round.  Voting again later changed no family's round
+    // count and cost 0.3 ms (measured), so the regions are listed once.
     HIPCHK(hipEventRecord(c->ev_fork, c->stream));
     HIPCHK(hipStreamWaitEvent(c->stream_other, c->ev_fork, 0));
     {
         hipStream_t so = c->stream_other;
         HIPCHK(hipMemsetAsync(B.pvote, 0, (size_t)nb * VT * 2 * sizeof(u32), so));
-        k2_vote0<<<xcd_grid((tiles + 3) / 4, nb), 64, 0, so>>>(B.keyB, B.n, B.huse, B.pvote, B.S, (tiles + 3) / 4, (u32)nb);
+        k2_vote0<<<xcd_grid((tiles + 3) / 4, nb), 64, 0, so>>>(part, B.n, B.huse, B.pvote, B.S, (tiles + 3) / 4, (u32)nb);
         KCHECK();
         k2_pick<<<nb, 256, 0, so>>>(B.pvote, B.n, B.cand, B.runs, nb);
         KCHECK();
@@ -1953,8 +2048,10 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
         KCHECK();
         HIPCHK(hipEventRecord(c->ev_join, so));
     }
-    lrerank<MODE_ROUND0>(c, nb, maxn, B.n, ST_ACTIVE, B.keyB, B.keyA);
+    // the last pass: `part` -> keyB (the sorted keys must end in keyB: the L-list is rebuilt into keyA)
+    radix_sort5(c, nb, maxn, B.n, part, part == B.keyA ? B.keyB : B.keyA, r0p0 == 1, r0p0, r0p0 - 1);
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    lrerank<MODE_ROUND0>(c, nb, maxn, B.n, ST_ACTIVE, B.keyB, B.keyA);
     // Round loop: k2_ctl of round r leaves its words in the control block (the round's own words are
     // double-buffered, each round zeroes its successor's: no memset in the loop), one small copy brings
     // them to a page-locked slot, and the host sizes the round's grids from them.  (Queueing round r
@@ -1975,10 +2072,10 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
         if (r == 0) {
             if (c->profile) {
                 // pass 0 reads the block bytes (1 B) instead of 8-byte keys
-                c->prof_bytes[P_RADIX_SCATTER] += ((r0p - 1) * 16.0 + 9.0) * (double)hc[8];
-                c->prof_bytes[P_RADIX_HIST] += ((r0p - 1) * 8.0 + 1.0) * (double)hc[8];
+                c->prof_bytes[P_RADIX_SCATTER] += ((r0p0 - 1) * 16.0 + 9.0) * (double)hc[8];
+                c->prof_bytes[P_RADIX_HIST] += ((r0p0 - 1) * 8.0 + 1.0) * (double)hc[8];
             }
-            c->st_sorted_elems += (u64)hc[8] * r0p;
+            c->st_sorted_elems += (u64)hc[8] * r0p0;
         }
         anyfin = hc[4] != 0;
         finS = hc[5];
