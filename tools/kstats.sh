@@ -2,7 +2,7 @@
 # kernel-time stats of bench.py under rocprofv3 (kernel trace only); prints the top kernels
 TAG=${1:-x}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/r2/ks_$TAG
+OUT=$ROOT/gpurun_out/r3q/ks_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu --no-host > $OUT/stats.log 2>&1
