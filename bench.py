@@ -43,7 +43,7 @@ PMC_NAME = {"k2_ssort": ["void k2_ssort<0>"],
 
 
 def load_pmc():
-    for name in ("r2c_pmc_traffic.json", "r2b_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+    for name in ("r3_pmc_traffic.json", "r2c_pmc_traffic.json", "r2b_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 return name, json.load(f)

@@ -219,7 +219,8 @@ __global__ __launch_bounds__(RT_THREADS) void k2_radix_hist(const u64 *__restric
                                                             u32 *__restrict__ tilehist, u32 S,
                                                             u32 TPB, int shift, u32 gtiles, u32 gnb,
                                                             const u8 *__restrict__ T,
-                                                            const u32 *__restrict__ present, u32 r0bits) {
+                                                            const u32 *__restrict__ present, u32 r0bits,
+                                                            const u8 *__restrict__ dig) {
     constexpr u32 RB = 1u << DB;
     XCD_MAP(gtiles, gnb)
     const u32 b = bz_b;
@@ -246,6 +247,20 @@ __global__ __launch_bounds__(RT_THREADS) void k2_radix_hist(const u64 *__restric
         return;
     }
     __syncthreads();
+    if (!FROM_T && DB == 8 && dig) {
+        // the scatter of the pass before left this pass's digit of every element, in list order, as one
+        // byte each: 1 B per element to read instead of the 8-byte word
+        typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = __builtin_nontemporal_load((const u32x4 *)(dig + (size_t)b * S + base) + threadIdx.x);
+        const u32 wv[4] = {v.x, v.y, v.z, v.w};
+        const u32 i0 = base + 16u * threadIdx.x;
+#pragma unroll
+        for (int q = 0; q < 16; q++)
+            if (i0 + q < n) atomicAdd(&hist[(wv[q >> 2] >> (8 * (q & 3))) & 255u], 1u);
+        __syncthreads();
+        for (u32 q = threadIdx.x; q < RB; q += RT_THREADS) th[q] = hist[q];
+        return;
+    }
     const u64 *kp = key + (size_t)b * S;
     typedef u64 u64x2 __attribute__((ext_vector_type(2)));
     const u64x2 *kp2 = (const u64x2 *)(kp + base); // base is a multiple of 4096: 16-byte aligned
@@ -336,7 +351,7 @@ __global__ __launch_bounds__(RT_THREADS, 4) void k2_radix_scatter(
     const u64 *__restrict__ keyIn, u64 *__restrict__ keyOut, const u32 *__restrict__ cntArr,
     const u32 *__restrict__ state, const u32 *__restrict__ tilehist,
     const u32 *__restrict__ digitbase, u32 S, u32 TPB, int shift, u32 gtiles, u32 gnb,
-    const u8 *__restrict__ T, const u32 *__restrict__ present, u32 r0bits) {
+    const u8 *__restrict__ T, const u32 *__restrict__ present, u32 r0bits, u8 *__restrict__ digOut) {
     constexpr u32 RB = 1u << DB;
     constexpr int PER = RB / 256;
     XCD_MAP(gtiles, gnb)
@@ -422,6 +437,9 @@ __global__ __launch_bounds__(RT_THREADS, 4) void k2_radix_scatter(
     }
     __syncthreads();
     u64 *ko = keyOut + (size_t)b * S;
+    // the next pass's digit of every element, at the element's new slot (one byte each: that pass's
+    // histogram then reads 1 B per element instead of 8)
+    u8 *dg = digOut ? digOut + (size_t)b * S : nullptr;
     if (!STAGE) {
         // straight from the registers: a bin's elements of one wave row go to consecutive slots
 #pragma unroll
@@ -430,6 +448,7 @@ __global__ __launch_bounds__(RT_THREADS, 4) void k2_radix_scatter(
             if (i < n) {
                 u32 d = (u32)(keys[k] >> shift) & (RB - 1u);
                 ko[gofs[d] + whist[w][d] + lr[k]] = keys[k]; // (not nontemporal: L2 merges these into full lines)
+                if (dg) dg[gofs[d] + whist[w][d] + lr[k]] = (u8)(keys[k] >> (shift + DB));
             }
         }
         return;
@@ -452,6 +471,7 @@ __global__ __launch_bounds__(RT_THREADS, 4) void k2_radix_scatter(
             const u64 kk = stage[j];
             const u32 d = (u32)(kk >> shift) & (RB - 1u);
             ko[gofs[d] + (j - binstart[d])] = kk; // (not nontemporal: L2 completes the lines shared by two tiles)
+            if (dg) dg[gofs[d] + (j - binstart[d])] = (u8)(kk >> (shift + DB));
         }
     }
 }
@@ -1928,21 +1948,26 @@ void run_present(bz2hip_ctx *c, int nb, u32 maxn) {
 // passes [first_pass, passes) of the sort; `a` is the input of pass `first_pass`, `bbuf` its output
 template <int DB, bool STG>
 static void radix_sort_db(bz2hip_ctx *c, int nb, u32 maxcnt, const u32 *cntArr, u64 *a, u64 *bbuf,
-                          int passes, bool from_T, int first_pass) {
+                          int passes, bool from_T, int first_pass, bool more_follow, bool dig_ready) {
     Batch &B = c->batch;
     const u32 tiles = (maxcnt + RTILE - 1) / RTILE;
     u64 *kin = a, *kout = bbuf;
+    // 8-bit passes hand the next pass its digits as a byte array (B.mtfpos is idle during the sort)
+    // (more_follow: a later call continues the sort, so the last pass here leaves digits too;
+    // dig_ready: the call before this one did)
+    const u8 *digIn = (DB == 8 && c->radix_dig && dig_ready) ? B.mtfpos : nullptr;
     for (int p = first_pass; p < passes; p++) {
         int shift = KEY_SHIFT + DB * p;
         const bool ft = from_T && p == 0;
+        u8 *digOut = (DB == 8 && c->radix_dig && (p + 1 < passes || more_follow)) ? B.mtfpos : nullptr;
         {
             ProfScope ps(c, P_RADIX_HIST);
             if (ft)
                 k2_radix_hist<true, DB><<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(
-                    kin, cntArr, B.state, B.tilehist, B.S, B.TPB, shift, tiles, nbarg(nb, 8), B.T, B.present, c->r0bits);
+                    kin, cntArr, B.state, B.tilehist, B.S, B.TPB, shift, tiles, nbarg(nb, 8), B.T, B.present, c->r0bits, nullptr);
             else
                 k2_radix_hist<false, DB><<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(
-                    kin, cntArr, B.state, B.tilehist, B.S, B.TPB, shift, tiles, nbarg(nb, 8), B.T, B.present, c->r0bits);
+                    kin, cntArr, B.state, B.tilehist, B.S, B.TPB, shift, tiles, nbarg(nb, 8), B.T, B.present, c->r0bits, digIn);
             KCHECK();
         }
         {
@@ -1955,13 +1980,14 @@ static void radix_sort_db(bz2hip_ctx *c, int nb, u32 maxcnt, const u32 *cntArr, 
             if (ft)
                 k2_radix_scatter<true, DB, STG><<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(
                     kin, kout, cntArr, B.state, B.tilehist, B.digitbase, B.S, B.TPB, shift, tiles, nbarg(nb, 8),
-                    B.T, B.present, c->r0bits);
+                    B.T, B.present, c->r0bits, digOut);
             else
                 k2_radix_scatter<false, DB, STG><<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(
                     kin, kout, cntArr, B.state, B.tilehist, B.digitbase, B.S, B.TPB, shift, tiles, nbarg(nb, 8),
-                    B.T, B.present, c->r0bits);
+                    B.T, B.present, c->r0bits, digOut);
             KCHECK();
         }
+        digIn = digOut;
         std::swap(kin, kout);
     }
 }
@@ -1972,14 +1998,15 @@ static int radix_passes(const bz2hip_ctx *c) { return 40 / (int)c->radix_bits; }
 // round 0 sorts r0bits key bits only (BZ2HIP_R0BITS; the default 40 = the whole field)
 static int radix_passes0(const bz2hip_ctx *c) { return ((int)c->r0bits + (int)c->radix_bits - 1) / (int)c->radix_bits; }
 static void radix_sort5(bz2hip_ctx *c, int nb, u32 maxcnt, const u32 *cntArr, u64 *a, u64 *bbuf,
-                        bool from_T = false, int passes = 0, int first_pass = 0) {
+                        bool from_T = false, int passes = 0, int first_pass = 0, bool more_follow = false,
+                        bool dig_ready = false) {
     if (!passes) passes = radix_passes(c);
     if (c->radix_bits == 10) {
-        if (c->radix_stage) radix_sort_db<10, true>(c, nb, maxcnt, cntArr, a, bbuf, passes, from_T, first_pass);
-        else radix_sort_db<10, false>(c, nb, maxcnt, cntArr, a, bbuf, passes, from_T, first_pass);
+        if (c->radix_stage) radix_sort_db<10, true>(c, nb, maxcnt, cntArr, a, bbuf, passes, from_T, first_pass, more_follow, dig_ready);
+        else radix_sort_db<10, false>(c, nb, maxcnt, cntArr, a, bbuf, passes, from_T, first_pass, more_follow, dig_ready);
     } else {
-        if (c->radix_stage) radix_sort_db<8, true>(c, nb, maxcnt, cntArr, a, bbuf, passes, from_T, first_pass);
-        else radix_sort_db<8, false>(c, nb, maxcnt, cntArr, a, bbuf, passes, from_T, first_pass);
+        if (c->radix_stage) radix_sort_db<8, true>(c, nb, maxcnt, cntArr, a, bbuf, passes, from_T, first_pass, more_follow, dig_ready);
+        else radix_sort_db<8, false>(c, nb, maxcnt, cntArr, a, bbuf, passes, from_T, first_pass, more_follow, dig_ready);
     }
 }
 
@@ -2023,7 +2050,7 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
     // passes go (T) -> keyB -> keyA -> ... -> keyB, so the "input" of pass 0 is nominally keyA.
     u64 *const A0 = (r0p0 & 1) ? B.keyA : B.keyB, *const B0 = (r0p0 & 1) ? B.keyB : B.keyA;
     // all passes but the last
-    radix_sort5(c, nb, maxn, B.n, A0, B0, true, r0p0 - 1);
+    radix_sort5(c, nb, maxn, B.n, A0, B0, true, r0p0 - 1, 0, /*more_follow=*/true);
     u64 *const part = ((r0p0 - 1) & 1) ? B0 : A0; // sorted by all key bits but the top digit
     // Repeat distances are voted for BEFORE the last pass, on the list sorted by the low key bits:
     // neighbours with equal (whole) keys are still neighbours there unless an element that differs
@@ -2049,7 +2076,8 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
         HIPCHK(hipEventRecord(c->ev_join, so));
     }
     // the last pass: `part` -> keyB (the sorted keys must end in keyB: the L-list is rebuilt into keyA)
-    radix_sort5(c, nb, maxn, B.n, part, part == B.keyA ? B.keyB : B.keyA, r0p0 == 1, r0p0, r0p0 - 1);
+    radix_sort5(c, nb, maxn, B.n, part, part == B.keyA ? B.keyB : B.keyA, r0p0 == 1, r0p0, r0p0 - 1, false,
+                /*dig_ready=*/r0p0 > 1);
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
     lrerank<MODE_ROUND0>(c, nb, maxn, B.n, ST_ACTIVE, B.keyB, B.keyA);
     // Round loop: k2_ctl of round r leaves its words in the control block (the round's own words are
@@ -2071,9 +2099,11 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
         const u32 *hr = hc + 16 + 16 * (r & 1);
         if (r == 0) {
             if (c->profile) {
-                // pass 0 reads the block bytes (1 B) instead of 8-byte keys
-                c->prof_bytes[P_RADIX_SCATTER] += ((r0p0 - 1) * 16.0 + 9.0) * (double)hc[8];
-                c->prof_bytes[P_RADIX_HIST] += ((r0p0 - 1) * 8.0 + 1.0) * (double)hc[8];
+                // pass 0 reads the block bytes (1 B) instead of 8-byte keys; with digit arrays every pass
+                // but the last writes 1 B more per element and every later histogram reads 1 B, not 8
+                const bool dg = c->radix_dig && c->radix_bits == 8;
+                c->prof_bytes[P_RADIX_SCATTER] += ((r0p0 - 1) * 16.0 + 9.0 + (dg ? r0p0 - 1 : 0)) * (double)hc[8];
+                c->prof_bytes[P_RADIX_HIST] += ((r0p0 - 1) * (dg ? 1.0 : 8.0) + 1.0) * (double)hc[8];
             }
             c->st_sorted_elems += (u64)hc[8] * r0p0;
         }
@@ -2089,8 +2119,9 @@ void run_bwt_n(bz2hip_ctx *c, int nb, u32 maxn) {
         if (!small_l) c->st_sorted_elems += (u64)hr[RC_SUML] * r0p;
         if (c->profile) {
             if (!small_l) {
-                c->prof_bytes[P_RADIX_SCATTER] += r0p * 16.0 * (double)hr[RC_SUML];
-                c->prof_bytes[P_RADIX_HIST] += r0p * 8.0 * (double)hr[RC_SUML];
+                const bool dg = c->radix_dig && c->radix_bits == 8;
+                c->prof_bytes[P_RADIX_SCATTER] += (r0p * 16.0 + (dg ? r0p - 1 : 0)) * (double)hr[RC_SUML];
+                c->prof_bytes[P_RADIX_HIST] += (dg ? 8.0 + (r0p - 1) : r0p * 8.0) * (double)hr[RC_SUML];
             }
             // keys: read E 8 + gather rank 4 + write E 8; ssort: read E 8 + write E 8 (LDS sort)
             c->prof_bytes[P_BWT_KEYS] += 20.0 * ((double)hr[RC_SUML] + (double)hr[RC_SUMS]);
