@@ -520,6 +520,22 @@ def main():
             res["decode"] = {"value": round(n_in / td / 1e6, 1), "unit": "MB/s", "ms": round(td * 1e3, 1),
                              "ok": bool(drc == 0 and dn == n_in and torch.equal(d_back[:dn], d_in))}
             del d_back
+            # several streams per call (bz2hip_decompress_streams): the stream just written, four times
+            # over, so that the per-block Huffman chains of > 1000 blocks run side by side
+            reps = 4
+            d_cat = d_out[:out_len].repeat(reps)
+            d_back = torch.empty(n_in * reps, dtype=torch.uint8, device=dev)
+            for _ in range(2):
+                torch.cuda.synchronize()
+                td = time.perf_counter()
+                drc, dn, dns = ctx.decompress_streams_device(d_cat.data_ptr(), out_len * reps, d_back.data_ptr(), n_in * reps)
+                torch.cuda.synchronize()
+                td = time.perf_counter() - td
+            res["decode_streams"] = {"value": round(n_in * reps / td / 1e6, 1), "unit": "MB/s", "ms": round(td * 1e3, 1),
+                                     "streams": int(dns), "blocks": int(ctx.last_stats()["blocks"]),
+                                     "ok": bool(drc == 0 and dn == n_in * reps and dns == reps and
+                                                torch.equal(d_back[n_in * (reps - 1):], d_in) and torch.equal(d_back[:n_in], d_in))}
+            del d_back, d_cat
         if world == 1 and not args.no_host:
             # SURVEY §8(d)'s definition: first byte submitted to last output byte in host memory,
             # through bz2hip_compress (PCIe both ways inside the clock).  Never `value`.

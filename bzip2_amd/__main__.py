@@ -4,8 +4,8 @@
 
 Compresses FILE to FILE.bz2 (or decompresses FILE.bz2 to FILE with -d) on GPU 0; with no file or
 with -c it reads stdin / writes stdout.  Decompression continues over concatenated streams
-(`cat a.bz2 b.bz2`), as the bzip2 tool does; the library call itself stops at the first end marker
-like the reference's decoder.  Needs the built library and a GPU: no CPU fallback."""
+(`cat a.bz2 b.bz2`), as the bzip2 tool does, through bz2hip_decompress_streams (one call per run of
+streams of one level).  Needs the built library and a GPU: no CPU fallback."""
 import argparse
 import os
 import sys
@@ -46,19 +46,20 @@ def main(argv=None):
         """every stream of z, concatenated -> (code, bytes)"""
         out = b""
         while True:
-            code, part = decode_one(z)
+            code, part = decode_run(z)
             out += part
             used = ctx.decode_consumed() if code == 0 else 0
             if code != 0 or used == 0 or used >= len(z) or z[used:used + 3] != b"BZh":
                 return code, out  # trailing bytes that are not a stream are ignored, as bzip2 does
             z = z[used:]
 
-    def decode_one(z):
+    def decode_run(z):
+        """the streams at the front of z that share the first one's level"""
         cap = max(len(z) * 6, 1 << 20)
         # no stream expands by more than ~1.24 million (a block of 255-runs: 45.9 MB from ~37 bytes)
         cap_max = len(z) * 1250000 + (1 << 20)
         while True:
-            code, out = ctx.decompress(z, cap)
+            code, out, _ = ctx.decompress_streams(z, cap)
             if code != -4 or cap >= cap_max:  # BZ2HIP_E_CAP: a block did not fit
                 return code, out
             cap = min(cap * 4, cap_max)

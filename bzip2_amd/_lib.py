@@ -23,6 +23,7 @@ SYMBOLS = [
     "bz2hip_stream_pending", "bz2hip_rle1_split", "bz2hip_bwt", "bz2hip_mtf_rle2",
     "bz2hip_huffman", "bz2hip_block_compress", "bz2hip_profile_reset", "bz2hip_profile_get", "bz2hip_last_stats3",
     "bz2hip_last_stats", "bz2hip_last_stats2", "bz2hip_decompress", "bz2hip_decompress_device",
+    "bz2hip_decompress_streams", "bz2hip_decompress_streams_device",
     "bz2hip_compress_device_noalloc", "bz2hip_shard_scan", "bz2hip_shard_chain",
     "bz2hip_shard_compress", "bz2hip_stitch_device", "bz2hip_host_alloc", "bz2hip_host_free",
     "bz2hip_tie_stats", "bz2hip_tie_stats2", "bz2hip_decode_consumed",
@@ -113,6 +114,10 @@ def load():
     L.bz2hip_decompress.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
     L.bz2hip_decompress_device.restype = C.c_int
     L.bz2hip_decompress_device.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz)]
+    L.bz2hip_decompress_streams.restype = C.c_int
+    L.bz2hip_decompress_streams.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(C.c_uint32)]
+    L.bz2hip_decompress_streams_device.restype = C.c_int
+    L.bz2hip_decompress_streams_device.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(C.c_uint32)]
     L.bz2hip_compress_device_noalloc.restype = C.c_int
     L.bz2hip_compress_device_noalloc.argtypes = [vp, vp, sz, C.c_int, vp, sz, C.POINTER(sz)]
     L.bz2hip_shard_scan.restype = C.c_int
@@ -244,6 +249,26 @@ class Context:
         if rc in (-1, -2, -3):
             self._chk(rc)
         return rc, out[: n.value].tobytes()
+
+    def decompress_streams(self, data, cap):
+        """concatenated streams of one level -> (rc, bytes, streams decoded completely)"""
+        a = np.frombuffer(bytes(data), dtype=np.uint8)
+        out = np.empty(max(cap, 1), dtype=np.uint8)
+        n = C.c_size_t(0)
+        ns = C.c_uint32(0)
+        rc = self.L.bz2hip_decompress_streams(self.h, _p(a), a.size, _p(out), cap, C.byref(n), C.byref(ns))
+        if rc in (-1, -2, -3):
+            self._chk(rc)
+        return rc, out[: n.value].tobytes(), ns.value
+
+    def decompress_streams_device(self, d_in_ptr, n, d_out_ptr, cap):
+        got = C.c_size_t(0)
+        ns = C.c_uint32(0)
+        rc = self.L.bz2hip_decompress_streams_device(self.h, C.c_void_p(d_in_ptr), n, C.c_void_p(d_out_ptr),
+                                                     cap, C.byref(got), C.byref(ns))
+        if rc in (-1, -2, -3):
+            self._chk(rc)
+        return rc, got.value, ns.value
 
     def decode_consumed(self):
         """input bytes the last successfully decoded stream occupied (concatenated streams continue there)"""

@@ -742,7 +742,7 @@ extern "C" int bz2hip_shard_compress(bz2hip_ctx *c, void *d_out, size_t cap, uin
 
 // ------------------------------------------------------------------ decoder (kd_decode.hip)
 int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size_t cap, size_t *produced,
-                   u32 *blocks_out);
+                   u32 *blocks_out, bool multi = false, u32 *streams_out = nullptr);
 
 extern "C" int bz2hip_decompress_device(bz2hip_ctx *c, const void *d_in, size_t n, void *d_out,
                                         size_t cap, size_t *produced) {
@@ -763,6 +763,34 @@ extern "C" int bz2hip_decompress(bz2hip_ctx *c, const uint8_t *in, size_t n, uin
         if (n) HIPCHK(hipMemcpyAsync(c->h_in, in, n, hipMemcpyHostToDevice, c->stream));
         u32 nblk = 0;
         int rc = run_decompress(c, c->h_in, n, c->h_out, cap, produced, &nblk);
+        c->st_blocks = nblk;
+        if (*produced) {
+            HIPCHK(hipMemcpyAsync(out, c->h_out, *produced, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+        }
+        return rc;
+    });
+}
+
+extern "C" int bz2hip_decompress_streams_device(bz2hip_ctx *c, const void *d_in, size_t n, void *d_out,
+                                                size_t cap, size_t *produced, uint32_t *n_streams) {
+    return guarded(c, [&]() -> int {
+        if (!produced || !n_streams || (n && !d_in) || (cap && !d_out)) return fail(c, BZ2HIP_E_PARAM, "null pointer");
+        u32 nblk = 0;
+        int rc = run_decompress(c, (const u8 *)d_in, n, (u8 *)d_out, cap, produced, &nblk, true, n_streams);
+        c->st_blocks = nblk;
+        return rc;
+    });
+}
+
+extern "C" int bz2hip_decompress_streams(bz2hip_ctx *c, const uint8_t *in, size_t n, uint8_t *out, size_t cap,
+                                         size_t *produced, uint32_t *n_streams) {
+    return guarded(c, [&]() -> int {
+        if (!produced || !n_streams || (n && !in) || (cap && !out)) return fail(c, BZ2HIP_E_PARAM, "null pointer");
+        ensure_staging(c, n, cap);
+        if (n) HIPCHK(hipMemcpyAsync(c->h_in, in, n, hipMemcpyHostToDevice, c->stream));
+        u32 nblk = 0;
+        int rc = run_decompress(c, c->h_in, n, c->h_out, cap, produced, &nblk, true, n_streams);
         c->st_blocks = nblk;
         if (*produced) {
             HIPCHK(hipMemcpyAsync(out, c->h_out, *produced, hipMemcpyDeviceToHost, c->stream));

@@ -1197,6 +1197,20 @@ __global__ void kd_set_meta(const u32 *__restrict__ list, u32 count, const u32 *
     origArr[b] = orig;
 }
 
+// The 16 stream bytes from the byte in which each decoded candidate ends (zero-filled past the end of
+// the input): where a stream ends there, they hold its end marker, its CRC and the header of the stream
+// that follows (at most 11 + 4 of them), which is all the host needs to walk on into that stream.
+__global__ void kd_tails(const u8 *__restrict__ in, size_t nbytes, const u32 *__restrict__ meta, u32 count,
+                         u8 *__restrict__ tails) {
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= count) return;
+    const u32 *mt = meta + (size_t)b * KM_WORDS;
+    const u64 end = (u64)mt[KM_END_LO] | ((u64)mt[KM_END_HI] << 32);
+    const u64 byte0 = end >> 3;
+    const bool ok = mt[KM_STATUS] == KS_OK;
+    for (u32 q = 0; q < 16; q++) tails[(size_t)b * 16 + q] = (ok && byte0 + q < nbytes) ? in[byte0 + q] : (u8)0;
+}
+
 // ------------------------------------------------------------------ host driver
 namespace {
 int map_status(u32 s) {
@@ -1228,10 +1242,16 @@ bool host_bits(const std::vector<u8> &buf, u64 buf_bit0, u64 nbits_total, u64 bi
 // Candidates are decoded KD_BATCH at a time (bounded workspace); the chain walk continues across
 // batches.
 #define KD_BATCH 1024
+// multi: after a stream's end marker go on with the stream that follows it in d_in, as long as one of
+// the same level does (concatenated streams, what pbzip2-style writers produce and the bzip2 tool
+// decodes; the reference's BZip2InputStream stops at the first end marker, S/BZip2InputStream.swift:
+// 201-242): the blocks of ALL streams are candidates of one scan and share the batches, so many small
+// streams fill the chip like one large one.  *streams_out = streams decoded completely.
 int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size_t cap, size_t *produced,
-                   u32 *blocks_out) {
+                   u32 *blocks_out, bool multi, u32 *streams_out) {
     *produced = 0;
     if (blocks_out) *blocks_out = 0;
+    if (streams_out) *streams_out = 0;
     c->dec_consumed = 0;
     hipStream_t st = c->stream;
     const u64 total_bits = (u64)nbytes * 8u;
@@ -1263,6 +1283,7 @@ int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size
     const u32 CH = S / KD_MCHUNK + 1; // chunks of the inverse MTF per block slot
     u32 *d_meta = nullptr, *d_slot = nullptr, *d_n = nullptr, *d_orig = nullptr, *d_base = nullptr, *d_merged = nullptr;
     u32 *d_order = nullptr;
+    u8 *d_tails = nullptr;
     uint2 *d_rinfo = nullptr, *d_visits = nullptr;
     u32 *d_nvis = nullptr, *d_cyc = nullptr, *d_outlen = nullptr, *d_flags = nullptr, *d_outbase = nullptr, *d_crc = nullptr;
     u32 *d_segstart = nullptr, *d_segres = nullptr, *d_segin = nullptr, *d_cagg = nullptr;
@@ -1285,6 +1306,7 @@ int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size
         d_segstart = A.get<u32>((size_t)NB * (KD_SEGS + 1)); d_segres = A.get<u32>((size_t)NB * KD_SEGS * 4);
         d_segin = A.get<u32>((size_t)NB * KD_SEGS * 2);
         d_cagg = A.get<u32>((size_t)NB * ETPB_MAX);
+        d_tails = A.get<u8>((size_t)NB * 16);
         return A.off;
     };
     auto ensure = [&](u32 NB) {
@@ -1329,9 +1351,10 @@ int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size
     if (ncand) HIPCHK(hipMemcpyAsync(d_cand, cand.data(), ncand * sizeof(u64), hipMemcpyHostToDevice, st));
     std::vector<u32> meta((size_t)NB * KM_WORDS);
 
-    u32 stream_crc = 0, nblocks = 0;
+    u32 stream_crc = 0, nblocks = 0, nstreams = 0;
     size_t out_total = 0;
     u64 cur = 32;
+    for (;;) { // streams (one unless `multi`)
     for (;;) {
         auto it = std::lower_bound(cand.begin(), cand.end(), cur);
         if (it == cand.end() || *it != cur) break; // not a block: end marker or garbage, below
@@ -1412,6 +1435,13 @@ int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size
         for (u32 g = 0; g < KD_GROUPS; g++)
             if (gbeg[g + 1] > gbeg[g]) HIPCHK(hipStreamSynchronize(gstream[g]));
         std::vector<u32> s_outlen(nbatch), s_flags(nbatch); // per candidate slot
+        std::vector<u8> s_tails;
+        if (multi) {
+            s_tails.resize((size_t)nbatch * 16);
+            kd_tails<<<(nbatch + 63) / 64, 64, 0, st>>>(d_in, nbytes, d_meta, nbatch, d_tails);
+            KCHECK();
+            HIPCHK(hipMemcpyAsync(s_tails.data(), d_tails, (size_t)nbatch * 16, hipMemcpyDeviceToHost, st));
+        }
         HIPCHK(hipMemcpyAsync(meta.data(), d_meta, (size_t)nbatch * KM_WORDS * sizeof(u32),
                               hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(s_outlen.data(), d_outlen, nbatch * 4, hipMemcpyDeviceToHost, st));
@@ -1419,10 +1449,36 @@ int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size
         HIPCHK(hipStreamSynchronize(st));
         // chain walk inside the batch, S/BZip2InputStream.swift:201-242
         std::vector<u32> chain; // batch slot of block k
+        // streams that end inside this batch with the next one's first block in it too: block `k` of the
+        // chain is the first of a new stream, `stored` the CRC the stream before it declares
+        struct Bound { u32 k, stored; size_t consumed; };
+        std::vector<Bound> bounds;
         int rc_huff = BZ2HIP_OK;
         for (;;) {
             auto jt = std::lower_bound(cand.begin() + i0, cand.begin() + i0 + nbatch, cur);
-            if (jt == cand.begin() + i0 + nbatch || *jt != cur) break;
+            if (jt == cand.begin() + i0 + nbatch || *jt != cur) {
+                // A stream that ends here and is followed by one whose first block this batch decoded
+                // too: walk on.  Everything else (last stream, damaged trailer, next batch) is the
+                // business of the code behind the batch loop, as for a single stream.
+                if (!multi || chain.empty()) break;
+                const u8 *t = &s_tails[(size_t)chain.back() * 16];
+                std::vector<u8> tv(t, t + 16);
+                const u64 b0 = cur >> 3;
+                u32 m1 = 0, m2 = 0, stored = 0;
+                if (!host_bits(tv, b0 * 8, total_bits, cur, 24, &m1) || !host_bits(tv, b0 * 8, total_bits, cur + 24, 24, &m2) ||
+                    m1 != 0x177245u || m2 != 0x385090u || !host_bits(tv, b0 * 8, total_bits, cur + 48, 32, &stored))
+                    break;
+                const size_t nb0 = (size_t)((cur + 80 + 7) / 8);
+                if (nb0 + 4 > nbytes) break;
+                const u8 *h = t + (nb0 - b0);
+                if (h[0] != 'B' || h[1] != 'Z' || h[2] != 'h' || (int)h[3] - '0' != level) break;
+                const u64 first = (u64)nb0 * 8u + 32u;
+                auto nt = std::lower_bound(cand.begin() + i0, cand.begin() + i0 + nbatch, first);
+                if (nt == cand.begin() + i0 + nbatch || *nt != first) break;
+                bounds.push_back({(u32)chain.size(), stored, nb0});
+                cur = first;
+                continue;
+            }
             const u32 ci = (u32)(jt - cand.begin()) - i0;
             const u32 *mt = &meta[(size_t)ci * KM_WORDS];
             if (mt[KM_STATUS] != KS_OK) { rc_huff = map_status(mt[KM_STATUS]); break; }
@@ -1452,6 +1508,23 @@ int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size
             int rc2 = BZ2HIP_OK;
             const char *msg2 = "";
             u32 k0 = 0;
+            size_t bi = 0;
+            // true = the stream that ends before block k of the chain fails its CRC (state set for the return)
+            auto at_bound = [&](u32 k, size_t out_before) -> bool {
+                if (bi >= bounds.size() || bounds[bi].k != k) return false;
+                if (bounds[bi].stored != stream_crc) {
+                    *produced = out_before;
+                    if (blocks_out) *blocks_out = nblocks + (k - k0);
+                    c->err = "BZip2 stream CRC error";
+                    return true;
+                }
+                stream_crc = 0;
+                nstreams++;
+                if (streams_out) *streams_out = nstreams;
+                c->dec_consumed = bounds[bi].consumed;
+                bi++;
+                return false;
+            };
             while (k0 < nb && rc2 == BZ2HIP_OK) {
                 std::vector<u32> h_base(1, 0);
                 u64 total = 0;
@@ -1484,6 +1557,7 @@ int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size
                     HIPCHK(hipMemcpyAsync(got.data(), d_crc, good * 4, hipMemcpyDeviceToHost, st));
                     HIPCHK(hipStreamSynchronize(st));
                     for (u32 k = 0; k < good; k++) {
+                        if (at_bound(k0 + k, out_total + h_base[k])) return BZ2HIP_E_STREAM_CRC;
                         if (got[k] != h_crc[k0 + k]) {
                             // the block's bytes are out before its CRC is compared (S/BZip2InputStream.swift:209-212)
                             *produced = out_total + h_base[k + 1];
@@ -1499,9 +1573,15 @@ int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size
                 *produced = out_total;
                 if (blocks_out) *blocks_out = nblocks;
                 k0 = k1;
+                // a pass that stopped at the first block of a stream: the stream before it is complete,
+                // and its CRC is compared before that block's error is reported
+                if (rc2 != BZ2HIP_OK && at_bound(k1, out_total)) return BZ2HIP_E_STREAM_CRC;
                 if (!good) break;
             }
             if (rc2 != BZ2HIP_OK) { c->err = msg2; return rc2; }
+            // a stream that ended with the last block of the chain (the block after it is the one that
+            // failed to decode, below)
+            if (at_bound(nb, out_total)) return BZ2HIP_E_STREAM_CRC;
         }
         if (rc_huff != BZ2HIP_OK) { c->err = "block could not be decoded"; return rc_huff; }
     }
@@ -1530,8 +1610,21 @@ int run_decompress(bz2hip_ctx *c, const u8 *d_in, size_t nbytes, u8 *d_out, size
             return BZ2HIP_E_STREAM_CRC;
         }
         c->dec_consumed = (size_t)((cur + 80 + 7) / 8); // the trailer is followed by zero padding to a byte
-        return BZ2HIP_OK;
+        nstreams++;
+        if (streams_out) *streams_out = nstreams;
+        if (!multi) return BZ2HIP_OK;
+        // another stream of the same level right behind this one?  (its header lies within the 16
+        // bytes fetched for the trailer: the trailer ends at most 11 bytes into them)
+        const size_t nb0 = c->dec_consumed;
+        if (nb0 + 4 > nbytes) return BZ2HIP_OK;
+        const u8 *h = tail.data() + (nb0 - byte0);
+        if ((nb0 - byte0) + 4 > tail.size() || h[0] != 'B' || h[1] != 'Z' || h[2] != 'h' || (int)h[3] - '0' != level)
+            return BZ2HIP_OK; // trailing bytes that are no such stream: the caller sees them at dec_consumed
+        cur = (u64)nb0 * 8u + 32u;
+        stream_crc = 0;
+        continue;
     }
     c->err = "BZip2 stream format error";
     return BZ2HIP_E_FORMAT;
+    } // streams
 }

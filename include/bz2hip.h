@@ -247,8 +247,25 @@ int bz2hip_decompress_device(bz2hip_ctx *ctx, const void *d_in, size_t n, void *
 /* Input bytes the stream of the last bz2hip_decompress* call occupied (header through stream CRC and
  * its zero padding), 0 unless it returned BZ2HIP_OK.  The reference's decoder stops at the first
  * end marker (S/BZip2InputStream.swift:201-242); a front end that wants the bzip2 tool's behaviour
- * for concatenated streams calls again at in + consumed (python -m bzip2_amd does). */
+ * for concatenated streams calls again at in + consumed, or uses bz2hip_decompress_streams.  After a
+ * _streams call: the bytes through the last stream that was decoded completely, whatever it returned. */
 int bz2hip_decode_consumed(bz2hip_ctx *ctx, size_t *consumed);
+
+/* Concatenated streams in one call: what a caller gets who constructs one BZip2InputStream
+ * (S/BZip2InputStream.swift:154-242) after the other over the same input until it is used up, with
+ * the outputs joined (the reference has no such loop of its own; the bzip2 tool and pbzip2-style
+ * writers define the format).  After a stream's end marker the call goes on with the stream that
+ * follows if its header names the SAME level as the first; it stops, with BZ2HIP_OK, at the end of the
+ * input or at bytes that are no such header (bz2hip_decode_consumed tells where: a caller continues
+ * there for a stream of another level).  The blocks of all streams are found by one scan and decoded
+ * in the same batches, so thousands of small streams fill the GPU like one large stream.
+ * An error is the one the failing stream's BZip2InputStream would throw; *produced then counts every
+ * earlier stream completely plus that stream's bytes before the error.  *n_streams = streams decoded
+ * completely. */
+int bz2hip_decompress_streams(bz2hip_ctx *ctx, const uint8_t *in, size_t n, uint8_t *out, size_t cap,
+                              size_t *produced, uint32_t *n_streams);
+int bz2hip_decompress_streams_device(bz2hip_ctx *ctx, const void *d_in, size_t n, void *d_out,
+                                     size_t cap, size_t *produced, uint32_t *n_streams);
 
 /* ---- profiling (profile=1): accumulated HIP-event time per kernel class --------------- */
 #define BZ2HIP_PROF_MAX 48

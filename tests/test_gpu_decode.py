@@ -183,3 +183,122 @@ def test_chain_longer_than_32bit_offsets_is_written_in_passes(orc):
             assert rc == -4 and rc == MAP[orc_rc] and out == orc_out, level
     finally:
         c.close()
+
+
+# ---- concatenated streams in one call (bz2hip_decompress_streams)
+def _streams_model(pieces, cap):
+    """What constructing one BZip2InputStream after the other over the joined pieces gives, from the
+    decoder oracle run per stream at its known offset: (rc, bytes, streams decoded completely)."""
+    z = b"".join(pieces)
+    out, off, level = b"", 0, None
+    for k, p in enumerate(pieces):
+        rest = z[off:]
+        if level is None:
+            level = rest[3:4]
+        elif len(rest) < 4 or rest[:3] != b"BZh" or rest[3:4] != level:
+            return 0, out, k, off
+        rc, got, _ = orc.decompress(rest, cap - len(out))
+        out += got
+        if rc != 0:
+            return MAP[rc], out, k, off
+        off += len(p)
+    return 0, out, len(pieces), off
+
+
+def test_concatenated_streams_decode_in_one_call(ctx):
+    rng = np.random.default_rng(77)
+    data = corpus.mixed(3, 21).tobytes()
+    parts = [data[:1200000], b"", data[1200000:1200007], data[1200007:2500000], b"x" * 70000, data[2500000:]]
+    pieces = [ctx.compress(p, 9) if k % 2 else bz2.compress(p, 9) for k, p in enumerate(parts)]
+    z = b"".join(pieces)
+    rc, out, ns = ctx.decompress_streams(z, len(data) + 70000)
+    assert rc == 0 and ns == len(parts) and out == b"".join(parts) == bz2.decompress(z)
+    assert ctx.decode_consumed() == len(z)
+    # the single-stream call still stops at the first end marker, like the reference
+    rc, one = ctx.decompress(z, len(data))
+    assert rc == 0 and one == parts[0] and ctx.decode_consumed() == len(pieces[0])
+    # trailing bytes that are no stream: ignored, and reported through decode_consumed
+    for junk in (b"\x00", b"garbage after the end", b"BZ", b"BZh", b"BZx9" + pieces[1][4:]):
+        rc, out, ns = ctx.decompress_streams(z + junk, len(data) + 70000)
+        assert rc == 0 and ns == len(parts) and out == b"".join(parts), junk[:8]
+        assert ctx.decode_consumed() == len(z)
+    # a stream of another level ends the call; the caller goes on from decode_consumed
+    other = [bz2.compress(parts[0], 5), ctx.compress(parts[3], 5)]
+    zz = pieces[0] + pieces[1] + other[0] + other[1] + pieces[4]
+    rc, out, ns = ctx.decompress_streams(zz, len(data))
+    used = ctx.decode_consumed()
+    assert rc == 0 and ns == 2 and out == parts[0] and used == len(pieces[0]) + len(pieces[1])
+    rc, out, ns = ctx.decompress_streams(zz[used:], len(data))
+    assert rc == 0 and ns == 2 and out == parts[0] + parts[3]
+    used += ctx.decode_consumed()
+    rc, out, ns = ctx.decompress_streams(zz[used:], len(data))
+    assert rc == 0 and ns == 1 and out == parts[4] and used + ctx.decode_consumed() == len(zz)
+    del rng
+
+
+def test_concatenated_streams_errors_are_those_of_the_failing_stream(ctx):
+    rng = np.random.default_rng(78)
+    data = corpus.mixed(1, 5).tobytes()
+    parts = [data[:260000], data[260000:300000], data[300000:650000], data[650000:700000]]
+    pieces = [bz2.compress(p, 1) for p in parts]
+    cap = 800000
+    offs = np.cumsum([0] + [len(p) for p in pieces])
+    cases = []
+    for j in range(len(pieces)):
+        n = len(pieces[j])
+        for pos, bit in ((n - 1, 1), (n - 3, 0x20), (n - 9, 4), (n // 2, 8), (12, 1), (5, 0x10), (3, 1), (0, 2)):
+            bad = list(pieces)
+            b = bytearray(bad[j]); b[pos] ^= bit; bad[j] = bytes(b)
+            cases.append((f"flip s{j} @{pos}", bad))
+        for _ in range(6):
+            bad = list(pieces)
+            b = bytearray(bad[j])
+            for _ in range(int(rng.integers(1, 3))):
+                b[int(rng.integers(4, n))] ^= 1 << int(rng.integers(0, 8))
+            bad[j] = bytes(b)
+            cases.append((f"rand s{j}", bad))
+    cases.append(("cut in the last trailer", pieces[:-1] + [pieces[-1][:-2]]))
+    cases.append(("cut in a block of the last stream", pieces[:-1] + [pieces[-1][:len(pieces[-1]) // 2]]))
+    cases.append(("only a header follows", pieces + [b"BZh1"]))
+    cases.append(("header and half a magic follow", pieces + [b"BZh1\x31\x41\x59"]))
+    for name, bad in cases:
+        want_rc, want_out, want_ns, want_used = _streams_model(bad, cap)
+        rc, out, ns = ctx.decompress_streams(b"".join(bad), cap)
+        if want_rc == MAP[orc.D_CAPACITY]:
+            assert rc == -4, name
+            continue
+        assert (rc, ns) == (want_rc, want_ns), (name, rc, ns, want_rc, want_ns)
+        assert out == want_out, name
+        assert ctx.decode_consumed() == want_used, name
+    # output buffer that ends inside stream 2: E_CAP with the blocks that fit
+    for cap2 in (offs[0] + 10, 260000, 260000 + 39999, 300000 + 120000, 699999):
+        cap2 = int(cap2)
+        want_rc, want_out, want_ns, _ = _streams_model(pieces, cap2)
+        rc, out, ns = ctx.decompress_streams(b"".join(pieces), cap2)
+        assert want_rc == MAP[orc.D_CAPACITY] and (rc, ns) == (-4, want_ns) and out == want_out, cap2
+
+
+def test_many_small_streams_share_the_batches(ctx):
+    """3000 streams of a few KB (more candidates than one batch holds): one scan, three batches."""
+    import torch
+    rng = np.random.default_rng(79)
+    data = corpus.mixed(8, 31).tobytes()
+    cuts = np.sort(rng.choice(len(data), 2999, replace=False))
+    parts = [data[a:b] for a, b in zip([0] + list(cuts), list(cuts) + [len(data)])]
+    pieces = [bz2.compress(p, 9) for p in parts]
+    z = b"".join(pieces)
+    rc, out, ns = ctx.decompress_streams(z, len(data))
+    assert rc == 0 and ns == 3000 and out == data
+    assert ctx.last_stats()["blocks"] >= 3000
+    # device form, and damage in a late stream: everything before it is delivered
+    d_in = torch.frombuffer(bytearray(z), dtype=torch.uint8).cuda()
+    d_out = torch.empty(len(data), dtype=torch.uint8, device="cuda")
+    rc, got, ns = ctx.decompress_streams_device(d_in.data_ptr(), d_in.numel(), d_out.data_ptr(), d_out.numel())
+    assert rc == 0 and got == len(data) and ns == 3000 and d_out.cpu().numpy().tobytes() == data
+    bad = bytearray(z)
+    bad[len(z) * 9 // 10] ^= 0x10
+    rc, out, ns = ctx.decompress_streams(bytes(bad), len(data))
+    ends = np.cumsum([len(p) for p in pieces])
+    assert rc != 0 and ns == int(np.searchsorted(ends, len(z) * 9 // 10, side="right")) and ns > 2048
+    done = sum(len(p) for p in parts[:ns])
+    assert out[:done] == data[:done]
