@@ -165,6 +165,7 @@ struct bz2hip_ctx {
     u32 plain_mask = 2;      // BZ2HIP_PLAIN
     u32 r0bits = 40;         // BZ2HIP_R0BITS
     u32 r0_sweeps = 2;       // BZ2HIP_RSWEEPS
+    bool mtf_inv = true;     // BZ2HIP_MTF_INV: MTF replay as inversion counts (k3_mtf_replay_inv) instead of the loop over run heads
     bool radix_dig = true;   // BZ2HIP_RADIX_DIG: a scatter pass leaves the next pass's digits as a byte array
     bool r0_rule = true;     // BZ2HIP_R0RULE: the run rule already in the re-rank of round 0
     bool radix_stage = true;  // BZ2HIP_RADIX_STAGE: order the tile by digit in LDS before the stores

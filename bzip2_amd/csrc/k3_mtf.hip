@@ -140,6 +140,150 @@ __global__ __launch_bounds__(256) void k3_mtf_replay(const u8 *__restrict__ bwt,
     else mtf_replay_body<4>(src, cbase, cend, smap, &ts[w][0], st, dst);
 }
 
+// ---- Replay without a list and without a loop over run heads: MTF positions as inversion counts.
+// Give every list entry a time: position t of the chunk has time t, the entry list's place i has time
+// -1 - i.  For position t let prev(t) be the time of the previous occurrence of its symbol.  The
+// symbols in front of it in the list are those whose last occurrence lies in (prev(t), t); every
+// time in that interval belongs to exactly one occurrence, and an occurrence is NOT the last one of
+// its symbol iff the symbol comes again at some c < t, i.e. iff prev(c) > prev(t) for a c < t:
+//     position(t) = t - prev(t) - 1 - #{c < t : prev(c) > prev(t)}
+// (a byte inside a run has prev = t - 1 and gets 0 by itself).  All prev(c) are distinct, so the count
+// is "processed positions minus the rank of prev(t) among their prevs": a bitmap over the 1280
+// possible times with per-word prefix counts, rebuilt after every 16 positions, plus the pairs
+// inside those 16 by DPP row shifts.  A quarter wave (one DPP row of 16 lanes) owns a chunk, so a wave
+// replays four chunks at once at ~100 instructions per 64 positions whatever the alphabet size; the
+// loop over run heads above costs 17-33 per head.
+#define MTI_CPW 4                       // chunks per wave (one per DPP row)
+#define MTI_WG_CHUNKS (4 * MTI_CPW)     // chunks per workgroup of 4 waves
+#define MTI_BMW 48                      // bitmap words per chunk (40 used: 1280 times)
+
+// (gfx9 has DPP operands on VOP1 / VOP2 only, not on compares: the two helpers below get their
+// conditions out of v_xor and of the borrow of v_subrev_co)
+#define MTI_ROW " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+
+// distance to the nearest earlier lane of the 16-lane row that holds the same value (0 = none);
+// values are >= 1 and < 2^27, lanes without a source read 0.  ((v[t-n] ^ v[t]) << 4 | n is n itself
+// for an equal lane and >= 16 otherwise: the minimum over n is the distance.)
+__device__ __forceinline__ u32 row16_nearest_equal(u32 v) {
+    u32 m = 0xffffu, x, y;
+#define MTI_EQ2(a, b)                                                                                  \
+    "v_xor_b32_dpp %1, %3, %3 row_shr:" #a MTI_ROW "v_lshl_or_b32 %2, %1, 4, " #a "\n\t"              \
+    "v_xor_b32_dpp %1, %3, %3 row_shr:" #b MTI_ROW "v_lshl_or_b32 %1, %1, 4, " #b "\n\t"              \
+    "v_min3_u32 %0, %0, %1, %2\n\t"
+    asm volatile("s_nop 1\n\t" MTI_EQ2(15, 14) MTI_EQ2(13, 12) MTI_EQ2(11, 10) MTI_EQ2(9, 8) MTI_EQ2(7, 6)
+                 MTI_EQ2(5, 4) MTI_EQ2(3, 2)
+                 "v_xor_b32_dpp %1, %3, %3 row_shr:1" MTI_ROW "v_lshl_or_b32 %1, %1, 4, 1\n\t"
+                 "v_min_u32_e32 %0, %0, %1\n\t"
+                 : "+v"(m), "=&v"(x), "=&v"(y)
+                 : "v"(v));
+#undef MTI_EQ2
+    return m < 16u ? m : 0u;
+}
+
+// number of earlier lanes of the 16-lane row whose value is greater (values < 2^32 - 1).  With a DPP
+// operand v_sub_co computes "shifted lane minus own lane" (measured: the reversed opcode does the
+// same), so the values are complemented: ~v[t-n] - ~v[t] borrows iff v[t-n] > v[t].  A lane without a
+// source reads 0 and always borrows: 15 - l such steps for lane l of the row.
+__device__ __forceinline__ u32 row16_greater_before(u32 v) {
+    u32 acc = 0, x;
+    const u32 w = ~v;
+#define MTI_GT(n)                                                                                      \
+    "v_sub_co_u32_dpp %1, vcc, %2, %2 row_shr:" #n MTI_ROW "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
+    asm volatile("s_nop 1\n\t" MTI_GT(15) MTI_GT(14) MTI_GT(13) MTI_GT(12) MTI_GT(11) MTI_GT(10) MTI_GT(9) MTI_GT(8)
+                 MTI_GT(7) MTI_GT(6) MTI_GT(5) MTI_GT(4) MTI_GT(3) MTI_GT(2) MTI_GT(1)
+                 : "+v"(acc), "=&v"(x)
+                 : "v"(w)
+                 : "vcc");
+#undef MTI_GT
+    return acc - (15u - ((u32)lane_id() & 15u));
+}
+
+// inclusive sum over the 16-lane row
+__device__ __forceinline__ u32 row16_incl_scan(u32 x) {
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);
+    return x;
+}
+
+__global__ __launch_bounds__(256) void k3_mtf_replay_inv(const u8 *__restrict__ bwt,
+                                                         const u32 *__restrict__ nArr,
+                                                         const u32 *__restrict__ present,
+                                                         const u8 *__restrict__ mtfrec,
+                                                         u8 *__restrict__ mtfpos, u32 S, u32 CPB) {
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    const u32 b = blockIdx.y;
+    const u32 n = nArr[b];
+    __shared__ u8 smap[256];
+    __shared__ __attribute__((aligned(16))) u8 buf[4][MTI_CPW * MTF_CHUNK]; // bytes in, positions out
+    __shared__ u32 lastP[4][MTI_CPW][256];                                   // symbol -> time + 256 of its last occurrence
+    __shared__ __attribute__((aligned(8))) uint2 bm[4][MTI_CPW][MTI_BMW];    // x = bitmap word, y = bits set in the words before
+    build_symbol_map(present + b * 8, smap);
+    __syncthreads();
+    const int w = wave_id(), lane = lane_id();
+    const u32 q = (u32)lane >> 4, l = (u32)lane & 15u;
+    const u32 wbase = (blockIdx.x * MTI_WG_CHUNKS + (u32)w * MTI_CPW) * MTF_CHUNK; // the wave's 4 chunks are contiguous
+    if (wbase >= n) return;
+    const u8 *src = bwt + (size_t)b * S;
+    u8 *dst = mtfpos + (size_t)b * S;
+    const u32 c = wbase / MTF_CHUNK + q;
+    const u32 cbase = c * MTF_CHUNK;
+    const u32 cend = min(cbase + MTF_CHUNK, n); // < cbase: a chunk past the end of the block
+    // the chunks' bytes (S is a multiple of 4096: the loads stay inside the block's slot)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const u32 u = (u32)r * 64u + (u32)lane;
+        *(u32x4 *)&buf[w][u * 16u] = *(const u32x4 *)(src + wbase + u * 16u);
+    }
+    // entry list -> times of the symbols' last occurrences before the chunk (place i: 255 - i)
+    if (cbase < n) {
+        const u32x4 e = *(const u32x4 *)(mtfrec + ((size_t)b * CPB + c) * 256 + l * 16u);
+#pragma unroll
+        for (int k = 0; k < 16; k++) lastP[w][q][(e[k >> 2] >> (8 * (k & 3))) & 255u] = 255u - (l * 16u + (u32)k);
+    }
+#pragma unroll
+    for (int k = 0; k < MTI_BMW / 16; k++) bm[w][q][l * (MTI_BMW / 16) + k] = make_uint2(0u, 0u);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    u32 *const lp = &lastP[w][q][0];
+    uint2 *const bmq = &bm[w][q][0];
+    u8 *const bq = &buf[w][q * MTF_CHUNK];
+    for (u32 k = 0; k < MTF_CHUNK / 16; k++) {
+        const u32 t = k * 16u + l;
+        const bool valid = cbase + t < cend;
+        const u32 sym = smap[bq[t]];
+        // previous occurrence: inside these 16 positions, else from the table
+        const u32 d = row16_nearest_equal(valid ? sym + 1u : 0x200u + l);
+        const u32 tp = lp[sym];
+        const u32 P = !valid ? 0u : (d ? 256u + t - d : tp);
+        if (valid) atomicMax(&lp[sym], 256u + t);
+        // processed positions with a greater prev: all 16 k of them minus those at or below P
+        const uint2 e = bmq[P >> 5];
+        const u32 below = (u32)__popc(e.x & ((1u << (P & 31u)) - 1u)) + e.y;
+        const u32 inv = k * 16u - below + row16_greater_before(valid ? P : 0u);
+        bq[t] = (u8)(t + 255u - P - inv);
+        if (valid) atomicOr(&bmq[P >> 5].x, 1u << (P & 31u));
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        // prefix counts again: lane l owns words 3 l .. 3 l + 2
+        const u32 w0 = bmq[l * 3u].x, w1 = bmq[l * 3u + 1u].x, w2 = bmq[l * 3u + 2u].x;
+        const u32 t1 = (u32)__popc(w0), t2 = t1 + (u32)__popc(w1), t3 = t2 + (u32)__popc(w2);
+        const u32 ex = row16_incl_scan(t3) - t3;
+        bmq[l * 3u].y = ex;
+        bmq[l * 3u + 1u].y = ex + t1;
+        bmq[l * 3u + 2u].y = ex + t2;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+    // positions out (units that start inside the block)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const u32 u = (u32)r * 64u + (u32)lane;
+        if (wbase + u * 16u < n) *(u32x4 *)(dst + wbase + u * 16u) = *(const u32x4 *)&buf[w][u * 16u];
+    }
+}
+
 // Recency list of a chunk without running the MTF: last occurrence of every symbol (LDS
 // atomic max), then rank the present symbols by last occurrence, latest first.
 __global__ __launch_bounds__(256) void k3_mtf_recency(const u8 *__restrict__ bwt,
@@ -589,7 +733,12 @@ void run_mtf(bz2hip_ctx *c, int nb, u32 maxn) {
     }
     {
         ProfScope ps(c, P_MTF_REPLAY, 2.0 * (double)maxn * nb); // read bwt 1 + write pos 1 (upper bound: slots)
-        k3_mtf_replay<<<gridc, 256, 0, c->stream>>>(B.bwt, B.n, B.present, B.mtfrec, B.mtfpos, B.S, CPB);
+        if (c->mtf_inv) {
+            const dim3 gridi((chunks + MTI_WG_CHUNKS - 1) / MTI_WG_CHUNKS, nb);
+            k3_mtf_replay_inv<<<gridi, 256, 0, c->stream>>>(B.bwt, B.n, B.present, B.mtfrec, B.mtfpos, B.S, CPB);
+        } else {
+            k3_mtf_replay<<<gridc, 256, 0, c->stream>>>(B.bwt, B.n, B.present, B.mtfrec, B.mtfpos, B.S, CPB);
+        }
         KCHECK();
     }
     {
