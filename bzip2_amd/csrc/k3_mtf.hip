@@ -155,30 +155,9 @@ __global__ __launch_bounds__(256) void k3_mtf_replay(const u8 *__restrict__ bwt,
 // loop over run heads above costs 17-33 per head.
 #define MTI_CPW 4                       // chunks per wave (one per DPP row)
 #define MTI_WG_CHUNKS (4 * MTI_CPW)     // chunks per workgroup of 4 waves
-#define MTI_BMW 48                      // bitmap words per chunk (40 used: 1280 times)
 
-// (gfx9 has DPP operands on VOP1 / VOP2 only, not on compares: the two helpers below get their
-// conditions out of v_xor and of the borrow of v_subrev_co)
+// (gfx9 has DPP operands on VOP1 / VOP2 only, not on compares: the condition comes out of a borrow)
 #define MTI_ROW " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-
-// distance to the nearest earlier lane of the 16-lane row that holds the same value (0 = none);
-// values are >= 1 and < 2^27, lanes without a source read 0.  ((v[t-n] ^ v[t]) << 4 | n is n itself
-// for an equal lane and >= 16 otherwise: the minimum over n is the distance.)
-__device__ __forceinline__ u32 row16_nearest_equal(u32 v) {
-    u32 m = 0xffffu, x, y;
-#define MTI_EQ2(a, b)                                                                                  \
-    "v_xor_b32_dpp %1, %3, %3 row_shr:" #a MTI_ROW "v_lshl_or_b32 %2, %1, 4, " #a "\n\t"              \
-    "v_xor_b32_dpp %1, %3, %3 row_shr:" #b MTI_ROW "v_lshl_or_b32 %1, %1, 4, " #b "\n\t"              \
-    "v_min3_u32 %0, %0, %1, %2\n\t"
-    asm volatile("s_nop 1\n\t" MTI_EQ2(15, 14) MTI_EQ2(13, 12) MTI_EQ2(11, 10) MTI_EQ2(9, 8) MTI_EQ2(7, 6)
-                 MTI_EQ2(5, 4) MTI_EQ2(3, 2)
-                 "v_xor_b32_dpp %1, %3, %3 row_shr:1" MTI_ROW "v_lshl_or_b32 %1, %1, 4, 1\n\t"
-                 "v_min_u32_e32 %0, %0, %1\n\t"
-                 : "+v"(m), "=&v"(x), "=&v"(y)
-                 : "v"(v));
-#undef MTI_EQ2
-    return m < 16u ? m : 0u;
-}
 
 // number of earlier lanes of the 16-lane row whose value is greater (values < 2^32 - 1).  With a DPP
 // operand v_sub_co computes "shifted lane minus own lane" (measured: the reversed opcode does the
@@ -207,6 +186,9 @@ __device__ __forceinline__ u32 row16_incl_scan(u32 x) {
     return x;
 }
 
+#define MTI_BUFSTRIDE (MTF_CHUNK + 16)  // LDS bytes per chunk: the four rows of a wave start 4 banks apart
+#define MTI_LPSTRIDE 264                // table words per chunk (256 used): rows 8 banks apart
+
 __global__ __launch_bounds__(256) void k3_mtf_replay_inv(const u8 *__restrict__ bwt,
                                                          const u32 *__restrict__ nArr,
                                                          const u32 *__restrict__ present,
@@ -216,9 +198,11 @@ __global__ __launch_bounds__(256) void k3_mtf_replay_inv(const u8 *__restrict__ 
     const u32 b = blockIdx.y;
     const u32 n = nArr[b];
     __shared__ u8 smap[256];
-    __shared__ __attribute__((aligned(16))) u8 buf[4][MTI_CPW * MTF_CHUNK]; // bytes in, positions out
-    __shared__ u32 lastP[4][MTI_CPW][256];                                   // symbol -> time + 256 of its last occurrence
-    __shared__ __attribute__((aligned(8))) uint2 bm[4][MTI_CPW][MTI_BMW];    // x = bitmap word, y = bits set in the words before
+    __shared__ __attribute__((aligned(16))) u8 buf[4][MTI_CPW * MTI_BUFSTRIDE]; // bytes in, positions out
+    __shared__ u32 lastP[4][MTI_CPW][MTI_LPSTRIDE];            // symbol -> time + 256 of its last occurrence (low half)
+    __shared__ __attribute__((aligned(16))) u32 bmx[4][256];   // per chunk 64 bitmap words (40 used), lane l of the row owns 4 l .. 4 l + 3
+    __shared__ __attribute__((aligned(16))) u32 bmy[4][256];   // bits set in the chunk's words before this one
+    __shared__ u32 sink[4][64];                                // where lanes write that have nothing to write
     build_symbol_map(present + b * 8, smap);
     __syncthreads();
     const int w = wave_id(), lane = lane_id();
@@ -230,57 +214,90 @@ __global__ __launch_bounds__(256) void k3_mtf_replay_inv(const u8 *__restrict__ 
     const u32 c = wbase / MTF_CHUNK + q;
     const u32 cbase = c * MTF_CHUNK;
     const u32 cend = min(cbase + MTF_CHUNK, n); // < cbase: a chunk past the end of the block
-    // the chunks' bytes (S is a multiple of 4096: the loads stay inside the block's slot)
+    // the chunks' bytes: load r brings chunk r, 16 bytes per lane (S is a multiple of 4096: the loads
+    // stay inside the block's slot)
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const u32 u = (u32)r * 64u + (u32)lane;
-        *(u32x4 *)&buf[w][u * 16u] = *(const u32x4 *)(src + wbase + u * 16u);
-    }
+    for (int r = 0; r < MTI_CPW; r++)
+        *(u32x4 *)&buf[w][r * MTI_BUFSTRIDE + lane * 16] = *(const u32x4 *)(src + wbase + r * MTF_CHUNK + lane * 16);
     // entry list -> times of the symbols' last occurrences before the chunk (place i: 255 - i)
     if (cbase < n) {
         const u32x4 e = *(const u32x4 *)(mtfrec + ((size_t)b * CPB + c) * 256 + l * 16u);
 #pragma unroll
         for (int k = 0; k < 16; k++) lastP[w][q][(e[k >> 2] >> (8 * (k & 3))) & 255u] = 255u - (l * 16u + (u32)k);
     }
-#pragma unroll
-    for (int k = 0; k < MTI_BMW / 16; k++) bm[w][q][l * (MTI_BMW / 16) + k] = make_uint2(0u, 0u);
+    ((u32x4 *)&bmx[w][0])[lane] = (u32x4){0u, 0u, 0u, 0u};
+    ((u32x4 *)&bmy[w][0])[lane] = (u32x4){0u, 0u, 0u, 0u};
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
     u32 *const lp = &lastP[w][q][0];
-    uint2 *const bmq = &bm[w][q][0];
-    u8 *const bq = &buf[w][q * MTF_CHUNK];
+    u32 *const bx = &bmx[w][q * 64u], *const by = &bmy[w][q * 64u];
+    u8 *const bq = &buf[w][q * MTI_BUFSTRIDE];
+    u32 *const mysink = &sink[w][lane];
+    // The LDS serves one wave's operations in order, so "insert, then read the words back" and "write
+    // the prefix counts, then look one up" need no wait of their own (the compiler's waits for the
+    // loaded values are enough); MTI_ORDER only keeps the compiler from moving them past each other.
+    // What the LDS does charge for is lanes of one instruction on one bank: atomics of a run of equal
+    // bytes all hit one word (the first version spent 77 % of its LDS cycles on conflicts), so runs
+    // inside the 16 positions are folded before anything touches the LDS: only a run's last lane
+    // marks the symbol, and a run's bits go into the bitmap as one range per word.
+#define MTI_ORDER() asm volatile("" ::: "memory")
+    const u32 mybit = 0x10000u << l, lowmask = (1u << l) - 1u;
+    u32 symn = smap[bq[l]];
     for (u32 k = 0; k < MTF_CHUNK / 16; k++) {
         const u32 t = k * 16u + l;
-        const bool valid = cbase + t < cend;
-        const u32 sym = smap[bq[t]];
-        // previous occurrence: inside these 16 positions, else from the table
-        const u32 d = row16_nearest_equal(valid ? sym + 1u : 0x200u + l);
-        const u32 tp = lp[sym];
-        const u32 P = !valid ? 0u : (d ? 256u + t - d : tp);
-        if (valid) atomicMax(&lp[sym], 256u + t);
-        // processed positions with a greater prev: all 16 k of them minus those at or below P
-        const uint2 e = bmq[P >> 5];
-        const u32 below = (u32)__popc(e.x & ((1u << (P & 31u)) - 1u)) + e.y;
-        const u32 inv = k * 16u - below + row16_greater_before(valid ? P : 0u);
+        const bool valid = cbase + t < cend; // lanes past the end of the block change nothing
+        const u32 sym = symn;
+        // runs: a lane whose left neighbour in the row holds the same byte continues it (prev = t - 1)
+        const u32 lsym = (u32)__builtin_amdgcn_update_dpp(0, (int)(sym + 1u), 0x111, 0xf, 0xf, true);
+        const bool cont = valid & (lsym == sym + 1u);
+        const u32 Cr = (u32)(__ballot(cont) >> (q * 16u)) & 0xffffu;  // the row's continuation lanes
+        const bool tail = valid & (((Cr >> (l + 1u)) & 1u) == 0u);     // last lane of its run
+        // Previous occurrence of the others.  The run tails mark themselves in the upper half of
+        // their symbol's table word; a lane then sees the time from before this step (lower half) and
+        // the tails of its symbol among the 16: the nearest one below it is its predecessor, and the
+        // tail with none above it writes the new time (which also clears the marks).
+        u32 *const slot = &lp[sym];
+        atomicOr(tail ? slot : mysink, mybit);
+        MTI_ORDER();
+        const u32 v = *slot;
+        const u32 nextb = bq[(t + 16u) & (MTF_CHUNK - 1u)]; // the next step's byte (the last step re-reads a position)
+        const u32 m = v >> 16, lower = m & lowmask;
+        const u32 pin = 256u + k * 16u + (31u - (u32)__clz(lower | 1u)); // the lane of the highest mark below this one
+        const u32 Ph = lower ? pin : (v & 0xffffu);
+        const u32 P = valid ? (cont ? 255u + t : Ph) : 0u;
+        MTI_ORDER();
+        *((tail & ((m >> (l + 1u)) == 0u)) ? slot : mysink) = 256u + t;
+        symn = smap[nextb];
+        // processed positions with a greater prev: all 16 k of them minus those below P
+        const u32 wi = P >> 5, pb = P & 31u;
+        const u32 below = (u32)__popc(bx[wi] & ((1u << pb) - 1u)) + by[wi];
+        const u32 inv = k * 16u - below + row16_greater_before(P);
+        MTI_ORDER();
         bq[t] = (u8)(t + 255u - P - inv);
-        if (valid) atomicOr(&bmq[P >> 5].x, 1u << (P & 31u));
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        // prefix counts again: lane l owns words 3 l .. 3 l + 2
-        const u32 w0 = bmq[l * 3u].x, w1 = bmq[l * 3u + 1u].x, w2 = bmq[l * 3u + 2u].x;
-        const u32 t1 = (u32)__popc(w0), t2 = t1 + (u32)__popc(w1), t3 = t2 + (u32)__popc(w2);
-        const u32 ex = row16_incl_scan(t3) - t3;
-        bmq[l * 3u].y = ex;
-        bmq[l * 3u + 1u].y = ex + t1;
-        bmq[l * 3u + 2u].y = ex + t2;
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
+        // insert: a run head its own bit; of a run's continuation lanes the first one, and any whose bit
+        // opens a word, the run's bits in that word
+        const bool leader = cont & ((pb == 0u) | ((((Cr << 1) >> l) & 1u) == 0u)); // (no short circuit: no branch)
+        const u32 rem = (u32)__builtin_ctz(~(Cr >> l));               // continuation lanes from this one on
+        const u32 range = ((1u << min(rem, 32u - pb)) - 1u) << pb;     // (rem >= 1 for a continuation lane)
+        const bool head = valid & !cont;
+        atomicOr((head | leader) ? &bx[wi] : mysink, head ? 1u << pb : range);
+        MTI_ORDER();
+        // prefix counts again: lane l owns words 4 l .. 4 l + 3
+        const u32x4 ww = ((const u32x4 *)&bmx[w][0])[lane];
+        const u32 c0 = (u32)__popc(ww.x), c1 = c0 + (u32)__popc(ww.y), c2 = c1 + (u32)__popc(ww.z),
+                  c3 = c2 + (u32)__popc(ww.w);
+        const u32 ex = row16_incl_scan(c3) - c3;
+        ((u32x4 *)&bmy[w][0])[lane] = (u32x4){ex, ex + c0, ex + c1, ex + c2};
+        MTI_ORDER();
     }
+#undef MTI_ORDER
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
     // positions out (units that start inside the block)
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const u32 u = (u32)r * 64u + (u32)lane;
-        if (wbase + u * 16u < n) *(u32x4 *)(dst + wbase + u * 16u) = *(const u32x4 *)&buf[w][u * 16u];
+    for (int r = 0; r < MTI_CPW; r++) {
+        const u32 o = wbase + (u32)r * MTF_CHUNK + (u32)lane * 16u;
+        if (o < n) *(u32x4 *)(dst + o) = *(const u32x4 *)&buf[w][r * MTI_BUFSTRIDE + lane * 16];
     }
 }
 
