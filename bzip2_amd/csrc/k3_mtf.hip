@@ -199,11 +199,20 @@ __global__ __launch_bounds__(256) void k3_mtf_replay_inv(const u8 *__restrict__ 
     const u32 n = nArr[b];
     __shared__ u8 smap[256];
     __shared__ __attribute__((aligned(16))) u8 buf[4][MTI_CPW * MTI_BUFSTRIDE]; // bytes in, positions out
-    __shared__ u32 lastP[4][MTI_CPW][MTI_LPSTRIDE];            // symbol -> time + 256 of its last occurrence (low half)
+    __shared__ u32 lastP[4][MTI_CPW][MTI_LPSTRIDE];            // byte -> time + 256 of its last occurrence (low half)
     __shared__ __attribute__((aligned(16))) u32 bmx[4][256];   // per chunk 64 bitmap words (40 used), lane l of the row owns 4 l .. 4 l + 3
     __shared__ __attribute__((aligned(16))) u32 bmy[4][256];   // bits set in the chunk's words before this one
     __shared__ u32 sink[4][64];                                // where lanes write that have nothing to write
+    __shared__ u8 sinv[256];                                   // dense symbol -> byte (absent bytes take the ids behind the present ones)
     build_symbol_map(present + b * 8, smap);
+    __syncthreads();
+    {
+        // The table below is indexed by the byte itself (no symbol lookup per position); only the entry
+        // lists speak in dense symbols.
+        const u32 v = threadIdx.x, uniq = (u32)smap[255] + ((present[b * 8 + 7] >> 31) & 1u);
+        const bool here = (present[b * 8 + (v >> 5)] >> (v & 31u)) & 1u;
+        sinv[here ? (u32)smap[v] : uniq + (v - (u32)smap[v])] = (u8)v;
+    }
     __syncthreads();
     const int w = wave_id(), lane = lane_id();
     const u32 q = (u32)lane >> 4, l = (u32)lane & 15u;
@@ -223,7 +232,7 @@ __global__ __launch_bounds__(256) void k3_mtf_replay_inv(const u8 *__restrict__ 
     if (cbase < n) {
         const u32x4 e = *(const u32x4 *)(mtfrec + ((size_t)b * CPB + c) * 256 + l * 16u);
 #pragma unroll
-        for (int k = 0; k < 16; k++) lastP[w][q][(e[k >> 2] >> (8 * (k & 3))) & 255u] = 255u - (l * 16u + (u32)k);
+        for (int k = 0; k < 16; k++) lastP[w][q][sinv[(e[k >> 2] >> (8 * (k & 3))) & 255u]] = 255u - (l * 16u + (u32)k);
     }
     ((u32x4 *)&bmx[w][0])[lane] = (u32x4){0u, 0u, 0u, 0u};
     ((u32x4 *)&bmy[w][0])[lane] = (u32x4){0u, 0u, 0u, 0u};
@@ -242,7 +251,7 @@ __global__ __launch_bounds__(256) void k3_mtf_replay_inv(const u8 *__restrict__ 
     // marks the symbol, and a run's bits go into the bitmap as one range per word.
 #define MTI_ORDER() asm volatile("" ::: "memory")
     const u32 mybit = 0x10000u << l, lowmask = (1u << l) - 1u;
-    u32 symn = smap[bq[l]];
+    u32 symn = bq[l];
     for (u32 k = 0; k < MTF_CHUNK / 16; k++) {
         const u32 t = k * 16u + l;
         const bool valid = cbase + t < cend; // lanes past the end of the block change nothing
@@ -267,7 +276,7 @@ __global__ __launch_bounds__(256) void k3_mtf_replay_inv(const u8 *__restrict__ 
         const u32 P = valid ? (cont ? 255u + t : Ph) : 0u;
         MTI_ORDER();
         *((tail & ((m >> (l + 1u)) == 0u)) ? slot : mysink) = 256u + t;
-        symn = smap[nextb];
+        symn = nextb;
         // processed positions with a greater prev: all 16 k of them minus those below P
         const u32 wi = P >> 5, pb = P & 31u;
         const u32 below = (u32)__popc(bx[wi] & ((1u << pb) - 1u)) + by[wi];
