@@ -67,6 +67,52 @@ def test_stage_mtf_rle2(ctx, orc):
         assert a == alpha and np.array_equal(f, freq), nm
 
 
+def test_mtf_replay_shapes(ctx, orc):
+    """The MTF stage alone on byte strings shaped for k3_mtf_replay_inv's corners: lengths around its
+    16-position steps, 1024-position chunks and 4-chunk waves; runs that cross steps, bitmap words and
+    chunks; a symbol that sits last in a chunk's entry list (time 0); 1 to 256 distinct bytes; equal
+    symbols 2..15 positions apart inside one step.  Both replay kernels must give the oracle's symbols."""
+    import bzip2_amd
+    rng = np.random.default_rng(4242)
+    cases = {}
+    for n in (1, 2, 15, 16, 17, 31, 32, 33, 1023, 1024, 1025, 4095, 4096, 4097, 5000, 16384 + 7):
+        cases[f"rand256_{n}"] = rng.integers(0, 256, n, dtype=np.uint8)
+        cases[f"rand3_{n}"] = rng.integers(65, 68, n, dtype=np.uint8)
+    cases["all_bytes_up_down"] = np.concatenate((np.arange(256), np.arange(255, -1, -1), np.arange(256))).astype(np.uint8)
+    cases["last_of_entry_list"] = np.concatenate((np.arange(256), rng.integers(1, 256, 3000), [0], rng.integers(0, 256, 500))).astype(np.uint8)
+    for period in (2, 3, 5, 15, 16, 17):
+        cases[f"period{period}"] = np.tile(rng.permutation(256)[:period].astype(np.uint8), 6000 // period + 1)
+    lens = rng.integers(1, 70, 4000)
+    cases["runs_1_70"] = np.repeat(rng.integers(0, 256, 4000, dtype=np.uint8), lens)
+    cases["runs_of_two_bytes"] = np.repeat(np.tile(np.array([7, 9], dtype=np.uint8), 1500), rng.integers(1, 40, 3000))
+    cases["long_runs"] = np.repeat(rng.integers(0, 256, 40, dtype=np.uint8), rng.integers(900, 1200, 40))
+    z = rng.integers(0, 256, 30000, dtype=np.uint8)
+    z[rng.integers(0, 30000, 20000)] = 32   # one dominant byte between others
+    cases["dominant_byte"] = z
+    cases["text"] = corpus.text(50000, 3)
+    names = list(cases)
+    bwts = [np.ascontiguousarray(cases[k], dtype=np.uint8) for k in names]
+    presents = []
+    for bw in bwts:
+        p = np.zeros(256, dtype=np.uint8)
+        p[np.unique(bw)] = 1
+        presents.append(p)
+    want = [orc.mtf_rle2(bw, p) for bw, p in zip(bwts, presents)]
+    for knob in ("1", "0"):
+        os.environ["BZ2HIP_MTF_INV"] = knob
+        try:
+            c = bzip2_amd.Context()
+        finally:
+            del os.environ["BZ2HIP_MTF_INV"]
+        try:
+            got = c.mtf_rle2(bwts, presents)
+        finally:
+            c.close()
+        for nm, (m, a, f), (gm, ga, gf) in zip(names, want, got):
+            assert np.array_equal(m, gm), (knob, nm)
+            assert a == ga and np.array_equal(f, gf), (knob, nm)
+
+
 def test_stage_huffman(ctx, orc):
     names, blocks, presents, _ = _blocks(orc, _cases())
     om = [orc.mtf_rle2(orc.bwt(b)[0], p) for b, p in zip(blocks, presents)]
