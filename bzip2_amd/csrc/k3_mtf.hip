@@ -343,7 +343,11 @@ __global__ __launch_bounds__(256) void k3_mtf_recency(const u8 *__restrict__ bwt
         for (int r = 0; r < MTF_CHUNK / 64; r++) {
             const u32 j = cbase + r * 64 + lane;
             sy[r] = smap[rowv[r]];
-            if (j < cend) atomicMax(&last[w][sy[r]], j - cbase + 1);
+            // only the last lane of a run inside the row: the lanes before it would raise the same
+            // word to smaller values (and lanes of one atomic on one word are served one by one)
+            const u32 right = (u32)__builtin_amdgcn_update_dpp((int)0x100, (int)(u32)sy[r], 0x130, 0xf, 0xf, false);
+            const bool covered = lane < 63 && right == (u32)sy[r] && j + 1 < cend;
+            if (j < cend && !covered) atomicMax(&last[w][sy[r]], j - cbase + 1);
         }
     }
     // wave-local: LDS operations of one wave complete in order
