@@ -228,9 +228,24 @@ __global__ __launch_bounds__(RT_THREADS) void k2_radix_hist(const u64 *__restric
     const u32 n = cntArr[b];
     const u32 base = bz_t * RTILE;
     if (base >= n) return;
-    __shared__ u32 hist[RB];
-    for (u32 q = threadIdx.x; q < RB; q += RT_THREADS) hist[q] = 0;
+    // Lanes of one LDS atomic that hit one word are served one after the other, and digits are
+    // anything but uniform (text, periodic data, zeros: 91 % of this kernel's LDS cycles were such
+    // conflicts): every bin exists HR times, lane l counts in copy l mod HR, and a thread that meets
+    // the same digit several times in a row adds the run at once.
+    constexpr u32 HR = DB == 8 ? 8u : 1u;
+    __shared__ u32 hist[RB * HR];
+    for (u32 q = threadIdx.x; q < RB * HR; q += RT_THREADS) hist[q] = 0;
     u32 *th = tilehist + ((size_t)b * TPB + bz_t) * RB;
+    const u32 hr = threadIdx.x & (HR - 1u);
+    auto flush = [&]() {
+        __syncthreads();
+        for (u32 q = threadIdx.x; q < RB; q += RT_THREADS) {
+            u32 sum = 0;
+#pragma unroll
+            for (u32 r = 0; r < HR; r++) sum += hist[q * HR + r];
+            th[q] = sum;
+        }
+    };
     if (FROM_T) {
         __shared__ R0Tile L;
         r0_tile_load(L, T, present, b, S, n, base);
@@ -240,10 +255,9 @@ __global__ __launch_bounds__(RT_THREADS) void k2_radix_hist(const u64 *__restric
         for (int k = 0; k < RT_ITEMS; k++) {
             const u32 local = k * RT_THREADS + threadIdx.x;
             if (base + local < n)
-                atomicAdd(&hist[(u32)(r0_key(L, local, base + local, d0, xb) >> shift) & (RB - 1u)], 1u);
+                atomicAdd(&hist[((u32)(r0_key(L, local, base + local, d0, xb) >> shift) & (RB - 1u)) * HR + hr], 1u);
         }
-        __syncthreads();
-        for (u32 q = threadIdx.x; q < RB; q += RT_THREADS) th[q] = hist[q];
+        flush();
         return;
     }
     __syncthreads();
@@ -254,11 +268,20 @@ __global__ __launch_bounds__(RT_THREADS) void k2_radix_hist(const u64 *__restric
         const u32x4 v = __builtin_nontemporal_load((const u32x4 *)(dig + (size_t)b * S + base) + threadIdx.x);
         const u32 wv[4] = {v.x, v.y, v.z, v.w};
         const u32 i0 = base + 16u * threadIdx.x;
+        u32 prev = wv[0] & 255u, run = i0 < n ? 1u : 0u;
 #pragma unroll
-        for (int q = 0; q < 16; q++)
-            if (i0 + q < n) atomicAdd(&hist[(wv[q >> 2] >> (8 * (q & 3))) & 255u], 1u);
-        __syncthreads();
-        for (u32 q = threadIdx.x; q < RB; q += RT_THREADS) th[q] = hist[q];
+        for (int q = 1; q < 16; q++) {
+            const u32 d = (wv[q >> 2] >> (8 * (q & 3))) & 255u;
+            const bool in = i0 + q < n;
+            if (in && d != prev) {
+                atomicAdd(&hist[prev * HR + hr], run);
+                prev = d;
+                run = 0;
+            }
+            run += in ? 1u : 0u;
+        }
+        if (run) atomicAdd(&hist[prev * HR + hr], run);
+        flush();
         return;
     }
     const u64 *kp = key + (size_t)b * S;
@@ -272,11 +295,10 @@ __global__ __launch_bounds__(RT_THREADS) void k2_radix_hist(const u64 *__restric
 #pragma unroll
     for (int k = 0; k < RT_ITEMS / 2; k++) {
         const u32 i = base + 2 * (k * RT_THREADS + threadIdx.x);
-        if (i < n) atomicAdd(&hist[(u32)(vv[k].x >> shift) & (RB - 1u)], 1u);
-        if (i + 1 < n) atomicAdd(&hist[(u32)(vv[k].y >> shift) & (RB - 1u)], 1u);
+        if (i < n) atomicAdd(&hist[((u32)(vv[k].x >> shift) & (RB - 1u)) * HR + hr], 1u);
+        if (i + 1 < n) atomicAdd(&hist[((u32)(vv[k].y >> shift) & (RB - 1u)) * HR + hr], 1u);
     }
-    __syncthreads();
-    for (u32 q = threadIdx.x; q < RB; q += RT_THREADS) th[q] = hist[q];
+    flush();
 }
 
 template <int DB>
