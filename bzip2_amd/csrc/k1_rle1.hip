@@ -588,9 +588,10 @@ __global__ __launch_bounds__(256) void k1_emit(const u8 *__restrict__ in,
     const u32 ebase = emit_base(in, agg_head, agg_c, binfo, b, s, gt);
     __shared__ u32 sm[8];
     __shared__ u32 red[8];
-    __shared__ u32 pres[8];
+    __shared__ u32 pres[8 * 8]; // the bitmap's 8 words, each 8 times (lane mod 8): atomics of one wave on one word are served one by one
     __shared__ __attribute__((aligned(16))) u8 stage[K1_EMIT_STAGE];
-    if (threadIdx.x < 8) pres[threadIdx.x] = 0;
+    if (threadIdx.x < 64) pres[threadIdx.x] = 0;
+    u32 *const mypres = pres + (threadIdx.x & 7u);
     EmitLane L;
     const u32 tot = emit_lane(in, agg_head, s, e, gt, sm, L);
     u32 total;
@@ -610,12 +611,12 @@ __global__ __launch_bounds__(256) void k1_emit(const u8 *__restrict__ in,
             const bool chunk_end = (k == 254u) || (i + 1 == e) || (cn != c);
             if (k < 4u) {
                 stage[o++] = (u8)c;
-                if (k == 0u) atomicOr(&pres[c >> 5], 1u << (c & 31));
+                if (k == 0u) atomicOr(&mypres[(c >> 5) * 8u], 1u << (c & 31));
             }
             if (chunk_end && k >= 3u) {
                 const u32 cb = k - 3u;
                 stage[o++] = (u8)cb;
-                atomicOr(&pres[cb >> 5], 1u << (cb & 31));
+                atomicOr(&mypres[(cb >> 5) * 8u], 1u << (cb & 31));
             }
         }
     }
@@ -639,7 +640,12 @@ __global__ __launch_bounds__(256) void k1_emit(const u8 *__restrict__ in,
         if (threadIdx.x < total - done) out[done + threadIdx.x] = stage[done + threadIdx.x];
     }
     if (threadIdx.x == 0 && gt == (e - 1) / K1_TILE) nOut[b] = ebase + total; // the block's last tile
-    if (threadIdx.x < 8 && pres[threadIdx.x]) atomicOr(&present[b * 8 + threadIdx.x], pres[threadIdx.x]);
+    if (threadIdx.x < 8) {
+        u32 v = 0;
+#pragma unroll
+        for (int r = 0; r < 8; r++) v |= pres[threadIdx.x * 8 + r];
+        if (v) atomicOr(&present[b * 8 + threadIdx.x], v);
+    }
 }
 
 // ---------------------------------------------------------------- CRC

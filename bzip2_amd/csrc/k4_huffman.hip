@@ -73,7 +73,10 @@ __global__ __launch_bounds__(256) void k4_select(const u16 *__restrict__ mtf,
     if (g0 >= ngroups) return;
     const int tables = (int)ntables[b];
     __shared__ u64 plen[HL];
-    __shared__ u32 hist[MAX_TABLES * HL];
+    // every counter four times (lane mod 4): the symbols are few and skewed (RUNA, RUNB, position 1),
+    // and lanes of one LDS atomic that meet on a word are served one by one
+    constexpr u32 HSR = 4;
+    __shared__ u32 hist[MAX_TABLES * HL * HSR];
     __shared__ u32 stage[HS_SUB * GROUP / 2];
     for (u32 j = threadIdx.x; j < HL; j += 256) {
         u64 p = 0;
@@ -81,7 +84,8 @@ __global__ __launch_bounds__(256) void k4_select(const u16 *__restrict__ mtf,
             p |= (u64)hlen[((size_t)b * MAX_TABLES + t) * HL + j] << (10 * t);
         plen[j] = p;
     }
-    for (u32 q = threadIdx.x; q < MAX_TABLES * HL; q += 256) hist[q] = 0;
+    for (u32 q = threadIdx.x; q < MAX_TABLES * HL * HSR; q += 256) hist[q] = 0;
+    const u32 hr = threadIdx.x & (HSR - 1u);
     const u16 *src = mtf + (size_t)b * S2;
     const u16 *st16 = (const u16 *)stage;
     for (u32 sub = 0; sub < HS_GROUPS_PER_WG / HS_SUB; sub++) {
@@ -108,13 +112,25 @@ __global__ __launch_bounds__(256) void k4_select(const u16 *__restrict__ mtf,
                     best = t;
                 }
             }
-            for (u32 i = 0; i < cnt; i++) atomicAdd(&hist[best * HL + st16[lbase + i]], 1u);
+            u32 *const hb = &hist[(u32)best * HL * HSR + hr];
+            u32 prev = st16[lbase], run = 1; // cnt >= 1; equal neighbours are added at once
+            for (u32 i = 1; i < cnt; i++) {
+                const u32 sy = st16[lbase + i];
+                if (sy != prev) {
+                    atomicAdd(&hb[prev * HSR], run);
+                    prev = sy;
+                    run = 0;
+                }
+                run++;
+            }
+            atomicAdd(&hb[prev * HSR], run);
             if (store) sel[(size_t)b * SEL_STRIDE + g] = (u8)best;
         }
     }
     __syncthreads();
     u32 *out = hpart + ((size_t)b * HS_PART_MAX + blockIdx.x) * MAX_TABLES * HL;
-    for (u32 q = threadIdx.x; q < MAX_TABLES * HL; q += 256) out[q] = hist[q];
+    for (u32 q = threadIdx.x; q < MAX_TABLES * HL; q += 256)
+        out[q] = hist[q * HSR] + hist[q * HSR + 1] + hist[q * HSR + 2] + hist[q * HSR + 3];
 }
 
 // ------------------------------------------------------------------ allocator (single lane)
