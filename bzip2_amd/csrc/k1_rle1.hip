@@ -649,7 +649,7 @@ __global__ __launch_bounds__(256) void k1_emit(const u8 *__restrict__ in,
 }
 
 // ---------------------------------------------------------------- CRC
-__constant__ u32 c_crc_table[256];
+__constant__ u32 c_crc_table4[4][256]; // [k][v]: the register after byte v and k zero bytes
 __constant__ u32 c_xpow16[257]; // x^(128*m) mod P, m = 0..256
 __constant__ u32 c_xpow1[16];   // x^(8*r) mod P, r = 0..15
 
@@ -663,34 +663,58 @@ __device__ __forceinline__ u32 gfmul(u32 a, u32 b) {
     return r;
 }
 
-// raw CRC (register from 0) of each 4096-byte tile of the block's input
+// raw CRC (register from 0) of each 4096-byte tile of the block's input.  One wave per tile, 64
+// contiguous bytes per lane: four table look-ups per 4 bytes (the four tables advance a byte by 0..3
+// further zero bytes), then ONE multiplication by x^(8 * bytes behind the lane's piece) and an xor
+// over the wave.  (16 bytes per lane and two 32-step multiplications each cost 26 instructions per
+// byte, and this kernel runs beside k1_emit, which needs the same issue slots.)
+#define K1_CRC_TPW 4 // tiles per workgroup
 __global__ __launch_bounds__(256) void k1_crc_p1(const u8 *__restrict__ in,
                                                  const u32 *__restrict__ starts,
                                                  u32 *__restrict__ cagg, u32 ETPB) {
     const u32 b = blockIdx.y;
     const u32 s = starts[b], e = starts[b + 1];
-    const u32 base = s + blockIdx.x * K1_TILE;
-    if (base >= e) return;
-    __shared__ u32 tab[256];
-    __shared__ u32 sm[8];
-    tab[threadIdx.x] = c_crc_table[threadIdx.x];
+    __shared__ u32 tab[4][256];
+#pragma unroll
+    for (int k = 0; k < 4; k++) tab[k][threadIdx.x] = c_crc_table4[k][threadIdx.x];
     __syncthreads();
+    const u32 tile = blockIdx.x * K1_CRC_TPW + (u32)wave_id();
+    const u32 base = s + tile * K1_TILE;
+    if (tile * K1_TILE >= e - s) return;
     const u32 tlen = min((u32)K1_TILE, e - base);
-    const u32 p0 = threadIdx.x * 16;
+    const u32 p0 = (u32)lane_id() * 64u;
     u32 reg = 0;
     if (p0 < tlen) {
-        u32 cnt = min(16u, tlen - p0);
-        for (u32 q = 0; q < cnt; q++) reg = (reg << 8) ^ tab[((reg >> 24) ^ in[base + p0 + q]) & 0xff];
-        u32 after = tlen - (p0 + cnt); // bytes after this piece inside the tile
-        u32 mult = gfmul(c_xpow16[after >> 4], c_xpow1[after & 15]);
+        const u32 cnt = min(64u, tlen - p0);
+        const u8 *a = in + base + p0;
+        if (cnt == 64u) {
+            // aligned words around the piece (the bytes outside it share a word with bytes inside)
+            const u32 m = (u32)((uintptr_t)a & 3u); // the same in every lane
+            const u32 *aw = (const u32 *)(a - m);
+            u32 D[17];
+#pragma unroll
+            for (int k = 0; k < 16; k++) D[k] = aw[k];
+            D[16] = m ? aw[16] : 0u;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const u32 wle = m == 0 ? D[k] : (m == 1 ? __builtin_amdgcn_alignbyte(D[k + 1], D[k], 1)
+                                                 : (m == 2 ? __builtin_amdgcn_alignbyte(D[k + 1], D[k], 2)
+                                                           : __builtin_amdgcn_alignbyte(D[k + 1], D[k], 3)));
+                const u32 x = reg ^ __builtin_bswap32(wle);
+                reg = tab[3][x >> 24] ^ tab[2][(x >> 16) & 255u] ^ tab[1][(x >> 8) & 255u] ^ tab[0][x & 255u];
+            }
+        } else {
+            for (u32 q = 0; q < cnt; q++) reg = (reg << 8) ^ tab[0][((reg >> 24) ^ a[q]) & 0xff];
+        }
+        const u32 after = tlen - (p0 + cnt); // bytes after this piece inside the tile
+        u32 mult = c_xpow16[after >> 4];
+        if (after & 15u) mult = gfmul(mult, c_xpow1[after & 15u]);
         reg = gfmul(reg, mult);
     }
     // xor-reduce
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) reg ^= __shfl_xor(reg, d, 64);
-    if (lane_id() == 0) sm[wave_id()] = reg;
-    __syncthreads();
-    if (threadIdx.x == 0) cagg[(size_t)b * ETPB + blockIdx.x] = sm[0] ^ sm[1] ^ sm[2] ^ sm[3];
+    if (lane_id() == 0) cagg[(size_t)b * ETPB + tile] = reg;
 }
 
 // Combines the tile CRCs of a block: crc = (init * x^(8 len) + sum_t raw_t * x^(8 * bytes after tile t)) ^ ~0.
@@ -767,7 +791,14 @@ void k1_init_tables(bz2hip_ctx *c) {
     u32 x128 = h_gfmul(xp1[15], x8);
     xp16[0] = 1;
     for (int m = 1; m <= 256; m++) xp16[m] = h_gfmul(xp16[m - 1], x128);
-    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_crc_table), tab, sizeof(tab)));
+    {
+        static u32 tab4[4][256];
+        for (u32 i = 0; i < 256; i++) {
+            tab4[0][i] = tab[i];
+            for (int k = 1; k < 4; k++) tab4[k][i] = (tab4[k - 1][i] << 8) ^ tab[tab4[k - 1][i] >> 24];
+        }
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_crc_table4), tab4, sizeof(tab4)));
+    }
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_xpow16), xp16, sizeof(xp16)));
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_xpow1), xp1, sizeof(xp1)));
     if (c->device >= 0 && c->device < 64) g_crc_tables_ready[c->device] = true;
@@ -858,7 +889,7 @@ void run_crc_blocks(bz2hip_ctx *c, const u8 *d_data, const u32 *d_starts, int nb
                     u32 *d_cagg, u32 ETPB, u32 *d_crc) {
     const u32 tiles = (max_len + K1_TILE - 1) / K1_TILE;
     if (tiles) {
-        k1_crc_p1<<<dim3(tiles, nb), 256, 0, c->stream>>>(d_data, d_starts, d_cagg, ETPB);
+        k1_crc_p1<<<dim3((tiles + K1_CRC_TPW - 1) / K1_CRC_TPW, nb), 256, 0, c->stream>>>(d_data, d_starts, d_cagg, ETPB);
         KCHECK();
     }
     k1_crc_p2<<<nb, 64, 0, c->stream>>>(d_starts, d_cagg, d_crc, nb, ETPB);
@@ -870,13 +901,12 @@ void run_rle1_emit(bz2hip_ctx *c, const u8 *d_in, const u32 *d_agg_head, const u
                    int nb, u32 max_in_len, u32 ETPB) {
     Batch &B = c->batch;
     const u32 tiles = (max_in_len + K1_TILE - 1) / K1_TILE;
-    dim3 grid(tiles, nb);
     // the emit tiles are the scan's global tiles: a block of `len` bytes touches up to one more
     dim3 egrid(std::min(tiles + 1, ETPB), nb);
     // The block CRCs depend only on the input and the block starts: they run on the other stream,
     // next to the emit scan; this stream waits for them before anything that follows.
     {
-        k1_crc_p1<<<grid, 256, 0, c->stream_other>>>(d_in, d_starts + b0, c->w_cagg, ETPB);
+        k1_crc_p1<<<dim3((tiles + K1_CRC_TPW - 1) / K1_CRC_TPW, nb), 256, 0, c->stream_other>>>(d_in, d_starts + b0, c->w_cagg, ETPB);
         KCHECK();
         k1_crc_p2<<<nb, 64, 0, c->stream_other>>>(d_starts + b0, c->w_cagg, B.crc, nb, ETPB);
         KCHECK();
