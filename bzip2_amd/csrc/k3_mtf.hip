@@ -644,8 +644,11 @@ __global__ __launch_bounds__(256) void k3_rle2_p3(const u8 *__restrict__ mtfpos,
     const u32 end = min(base + R2TILE, n + 1);
     const int w = wave_id(), lane = lane_id();
     __shared__ u32 wfirst[4], wlast[4], wsum[4];
-    __shared__ u32 hist[264];
-    for (u32 i = threadIdx.x; i < 264; i += 256) hist[i] = 0;
+    // every counter four times (lane mod 4): RUNA, RUNB and the first positions are most of the symbols,
+    // and lanes of one LDS atomic that meet on a word are served one by one
+    __shared__ u32 hist[264 * 4];
+    for (u32 i = threadIdx.x; i < 264 * 4; i += 256) hist[i] = 0;
+    u32 *const myhist = hist + (threadIdx.x & 3u);
     const u8 *mp = mtfpos + (size_t)b * S;
     const u32 *ag = r2agg + ((size_t)b * TPB + blockIdx.x) * 4;
     const u32 tile_off = ag[0], carry_in = ag[1];
@@ -724,19 +727,19 @@ __global__ __launch_bounds__(256) void k3_rle2_p3(const u8 *__restrict__ mtfpos,
                 for (;;) {
                     u32 dgt = rep & 1u;
                     out[o++] = (u16)dgt;
-                    atomicAdd(&hist[dgt], 1u);
+                    atomicAdd(&myhist[dgt * 4u], 1u);
                     if (rep <= 1) break;
                     rep = (rep - 2) >> 1;
                 }
             }
             u32 sym = (myv[k] == 0xffffu) ? eob : (myv[k] + 1);
             out[o] = (u16)sym;
-            atomicAdd(&hist[sym], 1u);
+            atomicAdd(&myhist[sym * 4u], 1u);
         }
     }
     __syncthreads();
     for (u32 i = threadIdx.x; i < 264; i += 256) {
-        u32 c = hist[i];
+        u32 c = hist[i * 4] + hist[i * 4 + 1] + hist[i * 4 + 2] + hist[i * 4 + 3];
         if (c) atomicAdd(&freq[b * 264 + i], c);
     }
 }
