@@ -388,6 +388,12 @@ class Context:
         self._chk(self.L.bz2hip_stream_read(self.h, _p(buf), cap, C.byref(n)))
         return buf[: n.value].tobytes()
 
+    def stream_read_into(self, out, offset=0):
+        """reads straight into the caller's uint8 array at `offset` (what a C caller does); -> bytes read"""
+        n = C.c_size_t(0)
+        self._chk(self.L.bz2hip_stream_read(self.h, C.c_void_p(out.ctypes.data + offset), out.size - offset, C.byref(n)))
+        return n.value
+
     def stream_pending(self):
         return self.L.bz2hip_stream_pending(self.h)
 

@@ -388,6 +388,19 @@ def test_streaming_api(ctx, orc):
     ctx.stream_begin(9)
     ctx.stream_finish()
     assert ctx.stream_read() == bytes.fromhex("425a683917724538509000000000")
+    # reads straight into the caller's buffer, interleaved with the writes (what bench.py's stream leg does)
+    sink = np.zeros(len(want) + 64, dtype=np.uint8)
+    ctx.stream_begin(4)
+    pos = got = 0
+    while pos < len(d):
+        ctx.stream_write(d[pos:pos + 250000])
+        pos += 250000
+        while ctx.stream_pending():
+            got += ctx.stream_read_into(sink, got)
+    ctx.stream_finish()
+    while ctx.stream_pending():
+        got += ctx.stream_read_into(sink, got)
+    assert got == len(want) and sink[:got].tobytes() == want
 
 
 def test_streaming_api_small_chunks(orc, monkeypatch):
