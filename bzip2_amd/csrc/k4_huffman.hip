@@ -245,9 +245,15 @@ __global__ __launch_bounds__(256) void k4_lengths(const u32 *__restrict__ mtflen
         a[rnk] = (int)((u32)kj >> 9);
     }
     __syncthreads();
+    // The allocator is one lane's work (~6 k dependent instructions): the other three waves end here and
+    // give their slots to the next tables (2600 level-1 blocks are 15 600 tables: the kernel is bound by
+    // how many of these workgroups a CU holds, not by the allocator's latency).
+    if (wave_id() != 0) return;
     if (threadIdx.x == 0) ha_allocate(a, alpha, 20);
-    __syncthreads();
-    for (int i = threadIdx.x; i < alpha; i += 256)
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    for (int i = threadIdx.x; i < alpha; i += 64)
         hlen[((size_t)b * MAX_TABLES + t) * HL + (sorted[i] & 0x1ff)] = (u8)a[i];
 }
 
