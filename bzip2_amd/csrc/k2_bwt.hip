@@ -174,12 +174,13 @@ __global__ __launch_bounds__(256) void k2_ctl(const u32 *__restrict__ nArr, u32 
 // present bitmap, the tile's bytes (+ the d0 - 1 that follow, cyclically) staged in LDS.
 struct R0Tile {
     u8 smap[256];
-    u8 t[RTILE + 64];
+    __attribute__((aligned(16))) u8 t[RTILE + 64]; // the tile's bytes as DENSE symbols (translated once, at the load)
     u32 uniq;
 };
 __device__ __forceinline__ void r0_tile_load(R0Tile &L, const u8 *__restrict__ T,
                                              const u32 *__restrict__ present, u32 b, u32 S, u32 n,
                                              u32 base) {
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
     {
         u32 v = threadIdx.x;
         const u32 *pw = present + b * 8;
@@ -189,20 +190,69 @@ __device__ __forceinline__ void r0_tile_load(R0Tile &L, const u8 *__restrict__ T
         L.smap[v] = (u8)cnt;
         if (v == 255) L.uniq = cnt + ((pw[7] >> 31) & 1u);
     }
+    __syncthreads();
+    // 16 bytes per thread and trip: one vector load where the 16 lie below n (base is a multiple of the
+    // tile and the slot is 16-byte aligned), single bytes with the cyclic continuation at the block's end
     const u8 *t = T + (size_t)b * S;
-    for (u32 q = threadIdx.x; q < RTILE + 64; q += RT_THREADS) {
-        u32 p = base + q;
-        if (p >= n) p = (p - n) % n; // cyclic continuation (n can be smaller than the overhang)
-        L.t[q] = t[p];
+    for (u32 u = threadIdx.x; u < (RTILE + 64) / 16; u += RT_THREADS) {
+        const u32 p0 = base + u * 16u;
+        u32 wv[4];
+        if (p0 + 16u <= n) {
+            const u32x4 v = *(const u32x4 *)(t + p0);
+            wv[0] = v.x; wv[1] = v.y; wv[2] = v.z; wv[3] = v.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                u32 x = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    u32 p = p0 + q * 4 + j;
+                    if (p >= n) p = (p - n) % n; // (n can be smaller than the overhang)
+                    x |= (u32)t[p] << (8 * j);
+                }
+                wv[q] = x;
+            }
+        }
+        u32 ov[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            ov[q] = (u32)L.smap[wv[q] & 255u] | ((u32)L.smap[(wv[q] >> 8) & 255u] << 8) |
+                    ((u32)L.smap[(wv[q] >> 16) & 255u] << 16) | ((u32)L.smap[wv[q] >> 24] << 24);
+        *(u32x4 *)&L.t[u * 16u] = (u32x4){ov[0], ov[1], ov[2], ov[3]};
     }
     __syncthreads();
 }
+// The key of rotation i (tile-local position `local`): its first d0 symbols as one number in base uniq,
+// then the bucket of the next symbol.  Alphabets of 33 symbols and more have d0 <= 7: the eight
+// symbols from `local` on come out of three LDS words, the first four fold in 32 bits.  Smaller
+// alphabets (up to 40 symbols deep) take the loop.
 __device__ __forceinline__ u64 r0_key(const R0Tile &L, u32 local, u32 i, u32 d0, u32 xb) {
-    u64 kk = 0;
+    u64 kk;
     const u32 uniq = L.uniq;
-    for (u32 q = 0; q < d0; q++) kk = kk * uniq + L.smap[L.t[local + q]];
+    u32 nxt; // the symbol behind the d0-th
+    if (d0 >= 4u && d0 <= 7u) {
+        const u32 *t32 = (const u32 *)L.t;
+        const u32 w = local >> 2, a = local & 3u;
+        const u32 w0 = t32[w], w1 = t32[w + 1], w2 = t32[w + 2];
+        const u32 lo = __builtin_amdgcn_alignbyte(w1, w0, a), hi = __builtin_amdgcn_alignbyte(w2, w1, a);
+        u32 k32 = lo & 255u;
+        k32 = k32 * uniq + ((lo >> 8) & 255u);
+        k32 = k32 * uniq + ((lo >> 16) & 255u);
+        k32 = k32 * uniq + (lo >> 24); // < uniq^4 <= 2^32
+        kk = k32;
+        u32 h = hi;
+        for (u32 q = 4; q < d0; q++) {
+            kk = kk * uniq + (h & 255u);
+            h >>= 8;
+        }
+        nxt = h & 255u;
+    } else {
+        kk = 0;
+        for (u32 q = 0; q < d0; q++) kk = kk * uniq + L.t[local + q];
+        nxt = L.t[local + d0];
+    }
     const u32 B = xb & 255u;
-    if (B > 1u) kk = kk * B + (((u32)L.smap[L.t[local + d0]] * (xb >> 8)) >> 16);
+    if (B > 1u) kk = kk * B + ((nxt * (xb >> 8)) >> 16);
     return (kk << KEY_SHIFT) | (u64)i;
 }
 
