@@ -373,44 +373,58 @@ __device__ __forceinline__ u32 sel_compose(u32 state, u32 rec, u32 seenmask) {
 // ------------------------------------------------------------------ block plan
 // one wave per block: selector MTF positions, section bit counts, total block bits.
 // hdr[b] = {bits before selectors, selector bits, table bits, data bits}
-__global__ __launch_bounds__(64) void k4_plan(const u32 *__restrict__ nsel,
-                                              const u32 *__restrict__ ntables,
-                                              const u32 *__restrict__ present,
-                                              const u8 *__restrict__ sel, u8 *__restrict__ selpos,
-                                              const u64 *__restrict__ tblbits,
-                                              u64 *__restrict__ hdr) {
+// One workgroup of four waves per block: every thread takes a stretch of the selectors (a block has
+// up to 18 002), the stretches' recency lists are composed along the wave (64 uniform steps from the
+// identity; a thread keeps the list and the seen set in front of its stretch), the four waves'
+// totals through LDS, and "state in front of the wave" composed with "what the wave's earlier threads
+// did" is the list a thread replays its stretch from.  (One wave per block was 146 us of pure latency.)
+__global__ __launch_bounds__(256) void k4_plan(const u32 *__restrict__ nsel,
+                                               const u32 *__restrict__ ntables,
+                                               const u32 *__restrict__ present,
+                                               const u8 *__restrict__ sel, u8 *__restrict__ selpos,
+                                               const u64 *__restrict__ tblbits,
+                                               u64 *__restrict__ hdr) {
     const u32 b = blockIdx.x;
-    const int lane = lane_id();
+    const int lane = lane_id(), w = wave_id();
     const u32 ns = nsel[b];
-    const u32 per = (ns + 63) / 64;
-    const u32 s0 = min(ns, lane * per), s1 = min(ns, s0 + per);
+    const u32 per = (ns + 255) / 256;
+    const u32 s0 = min(ns, threadIdx.x * per), s1 = min(ns, s0 + per);
     const u8 *sp = sel + (size_t)b * SEL_STRIDE;
     u8 *op = selpos + (size_t)b * SEL_STRIDE;
-    // phase A: chunk recency
+    __shared__ u32 wlist[4], wseen[4], wbits[4];
+    // phase A: the stretch's recency
     u32 list = SEL_IDENT, seen = 0;
     for (u32 i = s0; i < s1; i++) {
         u32 s = sp[i];
         sel_mtf(list, s);
         seen |= 1u << s;
     }
-    // serial compose over lanes (64 steps, uniform)
-    u32 state = SEL_IDENT, entry = SEL_IDENT;
+    // serial compose over the wave's lanes (64 steps, uniform), from the identity
+    u32 state = SEL_IDENT, sacc = 0, erl = SEL_IDENT, ers = 0;
     for (int l = 0; l < 64; l++) {
         u32 rl = __builtin_amdgcn_readlane(list, l);
         u32 sm = __builtin_amdgcn_readlane(seen, l);
-        if (lane == l) entry = state;
+        if (lane == l) { erl = state; ers = sacc; }
         state = sel_compose(state, rl, sm);
+        sacc |= sm;
     }
+    if (lane == 0) { wlist[w] = state; wseen[w] = sacc; }
+    __syncthreads();
+    u32 wstart = SEL_IDENT;
+    for (int q = 0; q < w; q++) wstart = sel_compose(wstart, wlist[q], wseen[q]);
     // phase B: replay
-    list = entry;
+    list = sel_compose(wstart, erl, ers);
     u32 bits = 0;
     for (u32 i = s0; i < s1; i++) {
         u32 p = sel_mtf(list, sp[i]);
         op[i] = (u8)p;
         bits += p + 1;
     }
-    u32 selbits = wave_reduce_add(bits);
-    if (lane == 0) {
+    bits = wave_reduce_add(bits);
+    if (lane == 0) wbits[w] = bits;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const u32 selbits = wbits[0] + wbits[1] + wbits[2] + wbits[3];
         u32 used16 = 0;
         for (int i = 0; i < 16; i++) {
             u32 wv = present[b * 8 + (i >> 1)];
@@ -827,7 +841,7 @@ void run_pack(bz2hip_ctx *c, int nb, u32 maxmtf, u8 *d_out, u64 first_bit, bool 
     const u32 PKT = (B.S + 64 + PK_TILE - 1) / PK_TILE;
     {
         ProfScope ps(c, P_HUF_HEADER);
-        k4_plan<<<nb, 64, 0, c->stream>>>(B.nsel, B.ntables, B.present, B.sel, B.selpos, B.tblbits,
+        k4_plan<<<nb, 256, 0, c->stream>>>(B.nsel, B.ntables, B.present, B.sel, B.selpos, B.tblbits,
                                           B.hdrbits);
         KCHECK();
         k4_offsets<<<1, 256, 0, c->stream>>>(B.hdrbits, B.bitoff, nb, first_bit, per_block ? 1 : 0,
