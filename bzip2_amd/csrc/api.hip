@@ -128,6 +128,7 @@ static void wfree(bz2hip_ctx *c) {
     c->w_rs = c->w_P = c->w_agg1 = c->w_agg2 = c->w_starts = c->w_cagg = nullptr;
     c->w_P16 = nullptr;
     c->w_binfo = nullptr;
+    c->w_hint = nullptr;
 }
 
 static u32 window_max_blocks(size_t wlen, int level) {
@@ -149,7 +150,8 @@ static size_t layout_window(bz2hip_ctx *c, size_t wlen, u32 mb, u8 *base) {
     u16 *p16 = A.get<u16>(wlen + 16);
     u32 *a1 = A.get<u32>(tiles), *a2 = A.get<u32>(tiles), *st = A.get<u32>((size_t)mb + 8);
     u32 *bi = A.get<u32>(2 * ((size_t)mb + 8));
-    if (base) { c->w_rs = rs; c->w_P = P; c->w_P16 = p16; c->w_binfo = bi; c->w_agg1 = a1; c->w_agg2 = a2; c->w_starts = st; }
+    u32 *hn = A.get<u32>(2 * cells);
+    if (base) { c->w_rs = rs; c->w_P = P; c->w_P16 = p16; c->w_binfo = bi; c->w_hint = hn; c->w_agg1 = a1; c->w_agg2 = a2; c->w_starts = st; }
     return A.off;
 }
 // per-batch CRC tile partials (the emit needs none since its tile offsets come from the scan)
@@ -285,8 +287,10 @@ extern "C" int bz2hip_create(bz2hip_ctx **out, const bz2hip_opts *opts) {
     c->device = dev;
     c->profile = c->opts.profile != 0;
     c->profile_level = c->opts.profile;
+    const int side_prio = env_int("BZ2HIP_SIDE_PRIO", 0);
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
-        hipStreamCreate(&c->stream_other) != hipSuccess) {
+        (side_prio ? hipStreamCreateWithPriority(&c->stream_other, hipStreamDefault, side_prio)
+                   : hipStreamCreate(&c->stream_other)) != hipSuccess) {
         g_create_err = "hipSetDevice/hipStreamCreate failed";
         delete c;
         return BZ2HIP_E_HIP;
@@ -302,6 +306,7 @@ extern "C" int bz2hip_create(bz2hip_ctx **out, const bz2hip_opts *opts) {
     c->r0_rule = env_int("BZ2HIP_R0RULE", 1) != 0;
     c->radix_dig = env_int("BZ2HIP_RADIX_DIG", 1) != 0;
     c->mtf_inv = env_int("BZ2HIP_MTF_INV", 1) != 0;
+    c->split_hints = env_int("BZ2HIP_SPLIT_HINTS", 1);
     c->tie_poison = env_int("BZ2HIP_TIE_POISON", 0) != 0; // tests: cached origin pointers are stored wrong
     c->stream_chunk = (size_t)std::max(1, env_int("BZ2HIP_STREAM_CHUNK_MIB", (int)(STREAM_CHUNK >> 20))) << 20;
     c->stream_sync = env_int("BZ2HIP_STREAM_SYNC", 0) != 0;
@@ -611,7 +616,7 @@ extern "C" int bz2hip_compress_device_noalloc(bz2hip_ctx *c, const void *d_in, s
             Batch batch;
             u32 *w_rs, *w_P, *w_agg1, *w_agg2, *w_starts, *w_cagg;
             u16 *w_P16;
-            u32 *w_binfo;
+            u32 *w_binfo, *w_hint;
             size_t w_cap;
             u32 w_maxblocks, w_ETPB;
             int w_eagg_nb;
@@ -619,7 +624,7 @@ extern "C" int bz2hip_compress_device_noalloc(bz2hip_ctx *c, const void *d_in, s
             explicit Saved(bz2hip_ctx *cc)
                 : c(cc), batch(std::move(cc->batch)), w_rs(cc->w_rs), w_P(cc->w_P), w_agg1(cc->w_agg1),
                   w_agg2(cc->w_agg2), w_starts(cc->w_starts), w_cagg(cc->w_cagg),
-                  w_P16(cc->w_P16), w_binfo(cc->w_binfo), w_cap(cc->w_cap), w_maxblocks(cc->w_maxblocks), w_ETPB(cc->w_ETPB),
+                  w_P16(cc->w_P16), w_binfo(cc->w_binfo), w_hint(cc->w_hint), w_cap(cc->w_cap), w_maxblocks(cc->w_maxblocks), w_ETPB(cc->w_ETPB),
                   w_eagg_nb(cc->w_eagg_nb), profile(cc->profile) {
                 cc->batch = Batch();
                 cc->fixed_ws = true;
@@ -631,6 +636,7 @@ extern "C" int bz2hip_compress_device_noalloc(bz2hip_ctx *c, const void *d_in, s
                 c->w_starts = w_starts; c->w_cagg = w_cagg;
                 c->w_P16 = w_P16;
                 c->w_binfo = w_binfo;
+                c->w_hint = w_hint;
                 c->w_cap = w_cap; c->w_maxblocks = w_maxblocks; c->w_ETPB = w_ETPB;
                 c->w_eagg_nb = w_eagg_nb;
                 c->profile = profile;

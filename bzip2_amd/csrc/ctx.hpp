@@ -156,6 +156,7 @@ struct bz2hip_ctx {
     u32 *w_starts = nullptr;
     u32 *w_binfo = nullptr;  // per block: end of its first run, P just after it (k1_split -> k1_emit)
     u16 *w_P16 = nullptr;    // flushed-length prefix per input byte, tile-local (k1_rle1.hip)
+    u32 *w_hint = nullptr;   // per 256-byte cell: bracket of the end of a block that starts there (k1_hints)
     u32 *w_cagg = nullptr;   // CRC tile partials [batch blocks][w_ETPB] (used on the other stream)
     void *w_region = nullptr;  // device region holding rs / P / aggregates / starts
     void *w_eregion = nullptr; // device region holding the emit / CRC tile partials
@@ -165,7 +166,8 @@ struct bz2hip_ctx {
     u32 plain_mask = 2;      // BZ2HIP_PLAIN
     u32 r0bits = 40;         // BZ2HIP_R0BITS
     u32 r0_sweeps = 2;       // BZ2HIP_RSWEEPS
-    bool mtf_inv = true;     // BZ2HIP_MTF_INV: MTF replay as inversion counts (k3_mtf_replay_inv) instead of the loop over run heads
+    bool mtf_inv = true;
+    int split_hints = 1;     // k1_hints before the block chain: 0 never, 1 when more than 8 blocks lie ahead, 2 always (tests)     // BZ2HIP_MTF_INV: MTF replay as inversion counts (k3_mtf_replay_inv) instead of the loop over run heads
     bool radix_dig = true;   // BZ2HIP_RADIX_DIG: a scatter pass leaves the next pass's digits as a byte array
     bool r0_rule = true;     // BZ2HIP_R0RULE: the run rule already in the re-rank of round 0
     bool radix_stage = true;  // BZ2HIP_RADIX_STAGE: order the tile by digit in LDS before the stores

@@ -275,6 +275,103 @@ __device__ bool wave_bracket(const ARR arr, u32 lo, u32 hi, u32 thr, u32 *nlo, u
     return true;
 }
 
+// ---------------------------------------------------------------- split hints
+// Where a block ends depends on where it starts only through a threshold on P that lies within
+// +-10 of P(s) + limit (header comment; the cut first run shifts it by at most two flushes).  So
+// for every cell start g = 256 c, in parallel, before the chain:
+//   hint[2c]     = last e in [g, n] with P(e) <= P(g) + limit - 16
+//   hint[2c + 1] = a position shortly after it with P(e) > P(g) + limit + 16, or n
+// and a block that starts in cell c ends in (hint[2c], hint[2(c+1) + 1]]: about 300 positions for
+// run-free data, which the chain settles with one probe level instead of a search from scratch.
+// The chain checks the bracket against its own threshold and falls back to the search when it
+// does not hold, so the table is an accelerator only.
+#define K1_HINT_SLACK 16u
+__device__ __forceinline__ u32 hint_last_le(const u32 *__restrict__ Pc, const PrefixArr &P, u32 n, u32 c0,
+                                            u32 c1, u32 T) {
+    u32 lo = c0, hi = c1; // P(256 lo) <= T; the answer's cell is in [lo, hi]
+    while (lo < hi) {
+        const u32 mid = (lo + hi + 1u) >> 1;
+        if (Pc[mid] + P.agg[mid / K1_CPT] <= T) lo = mid;
+        else hi = mid - 1u;
+    }
+    u32 a = lo * K1_CELL, b = min(a + K1_CELL - 1u, n);
+    while (a < b) {
+        const u32 mid = (a + b + 1u) >> 1;
+        if (P(mid) <= T) a = mid;
+        else b = mid - 1u;
+    }
+    return a;
+}
+__global__ __launch_bounds__(256) void k1_hints(const u32 *__restrict__ Pc, const u16 *__restrict__ Ploc,
+                                                const u32 *__restrict__ agg_c, u32 n, u32 block_size,
+                                                u32 *__restrict__ hint) {
+    // a wave takes 64 consecutive cells: their answers are consecutive too, so the whole wave first
+    // finds the cell of lane 0's answer (64-ary, 3 levels for any block size) and every lane then
+    // searches the 128 cells from there on
+    const u32 lane = (u32)lane_id();
+    const u32 cw = (blockIdx.x * 4u + (u32)wave_id()) * 64u;
+    const u32 last = n / K1_CELL; // cells 0..last have a record (k1_cells, k1_sentinels)
+    if (cw > last) return;
+    const u32 c = min(cw + lane, last);
+    const PrefixArr P{Ploc, agg_c};
+    const u32 limit = block_size - 6u;
+    // a block never swallows more than ~51x its size of input (k1_split)
+    const u32 span = (u32)(((u64)block_size * 52ull + 1024ull) / K1_CELL + 2ull);
+    const u32 c1 = (u32)min((u64)last, (u64)c + span);
+    const u32 Tlo = Pc[c] + agg_c[c / K1_CPT] + limit - K1_HINT_SLACK;
+    const u32 T0 = (u32)__builtin_amdgcn_readfirstlane((int)Tlo);
+    u32 a0 = cw;
+    {
+        u32 lo = cw, hi = (u32)min((u64)last, (u64)cw + span); // P(256 lo) <= T0; answer cell in [lo, hi]
+        while (lo < hi) {
+            const u32 step = (hi - lo + 63u) / 64u;
+            const u32 idx = min(lo + (lane + 1u) * step, hi);
+            const u32 k = (u32)__popcll(__ballot(Pc[idx] + agg_c[idx / K1_CPT] <= T0)); // a prefix of the lanes
+            const u32 nlo = min(lo + k * step, hi);
+            hi = min(lo + (k + 1u) * step - 1u, hi);
+            lo = nlo;
+        }
+        a0 = lo;
+    }
+    u32 lo = max(a0, c), hi = min(a0 + 128u, c1);
+    if (hi < lo) hi = lo;
+    if (hi < c1 && Pc[hi] + agg_c[hi / K1_CPT] <= Tlo) { // the window is too short (answers in a region of long runs)
+        lo = hi;
+        hi = c1;
+    }
+    const u32 e_lo = hint_last_le(Pc, P, n, lo, hi, Tlo);
+    // upper end: any position whose P exceeds the upper threshold will do, as long as it is near
+    const u32 Thi = Tlo + 2u * K1_HINT_SLACK;
+    const u32 q1 = min(e_lo + 64u, n), q2 = min(e_lo + 256u, n);
+    const u32 p1 = P(q1), p2 = P(q2);
+    u32 e_hi;
+    if (p1 > Thi || q1 == n) e_hi = q1;
+    else if (p2 > Thi || q2 == n) e_hi = q2;
+    else e_hi = min(hint_last_le(Pc, P, n, q2 / K1_CELL, max(c1, q2 / K1_CELL), Thi) + 1u, n);
+    if (cw + lane <= last) {
+        hint[2 * c] = e_lo;
+        hint[2 * c + 1] = e_hi;
+    }
+}
+
+// The first i in (lo, hi] with arr[i] > thr when hi - lo <= 512 and arr(lo) <= thr < arr(hi): one
+// level of 512 probes.  false when the range does not bracket it.
+template <typename ARR>
+__device__ bool wave_bracket_exact(const ARR arr, u32 lo, u32 hi, u32 thr, u32 *e) {
+    const u32 lane = (u32)lane_id();
+    const u32 vlo = arr(lo);
+    u32 best = 512;
+#pragma unroll
+    for (int j = 7; j >= 0; j--) {
+        const u32 idx = min(lo + 1u + (u32)j * 64u + lane, hi);
+        const u64 m = __ballot(arr(idx) > thr);
+        if (m) best = (u32)j * 64u + (u32)(__ffsll((unsigned long long)m) - 1);
+    }
+    if (vlo > thr || best == 512) return false;
+    *e = min(lo + 1u + best, hi);
+    return true;
+}
+
 // ---------------------------------------------------------------- cells, read side (one wave)
 struct CellArrs {
     const u8 *in;
@@ -361,7 +458,8 @@ __global__ __launch_bounds__(64) void k1_split(const u8 *__restrict__ in, const 
                                                const u32 *__restrict__ agg_c, u32 n, u32 block_size,
                                                u32 max_blocks, u32 *__restrict__ starts,
                                                u32 *__restrict__ binfo,
-                                               u32 *__restrict__ count_out, u32 s0, u32 stop) {
+                                               u32 *__restrict__ count_out, u32 s0, u32 stop,
+                                               const u32 *__restrict__ hint) {
     const u32 limit = block_size - 6;
     const PrefixArr P{Ploc, agg_c};
     const CellArrs A{in, Hc, Pc, agg_c, n};
@@ -371,10 +469,15 @@ __global__ __launch_bounds__(64) void k1_split(const u8 *__restrict__ in, const 
         if (lane_id() == 0) starts[cnt] = s;
         // end of the run containing s: almost always within the next 64 bytes; the same step
         // fetches P(idx + 1), which is P(re0 + 1) for the lane that finds the run end
-        u32 re0, p_re0p1 = 0;
+        u32 re0, p_re0p1 = 0, h_lo = 0, h_hi = 0;
         bool have_p = false;
         {
             const u32 idx = s + 1u + (u32)lane_id();
+            if (hint) { // the bracket of this block's end, requested with the run-end probe
+                const u32 hc = s / K1_CELL;
+                h_lo = hint[2 * hc];
+                h_hi = hc < cmax ? hint[2 * hc + 3] : n;
+            }
             // a head at idx (the end of the data counts as one)
             const u32 hb = in[min(idx, n - 1)], hbp = in[min(idx - 1u, n - 1)];
             const bool pred = idx <= n && (idx == n || hb != hbp);
@@ -422,8 +525,16 @@ __global__ __launch_bounds__(64) void k1_split(const u8 *__restrict__ in, const 
                 // blocks of one kind of data are about equally long.  When the last block was as long as
                 // the one before (run-free data: always bs - 4 bytes), one probe of the 64 positions
                 // around "as long again" settles this block in a single dependent load.
-                bool done = false;
-                if (plen && perr == 0) {
+                bool done = false, br = false;
+                u32 nlo = 0, nhi = 0;
+                if (hint) {
+                    const u32 lo2 = max(re0, h_lo), hi2 = min(hi, h_hi);
+                    if (lo2 < hi2) {
+                        if (hi2 - lo2 <= 512u) done = wave_bracket_exact(P, lo2, hi2, thr, &e);
+                        else br = wave_bracket(P, lo2, hi2, thr, &nlo, &nhi);
+                    }
+                }
+                if (!done && !br && plen && perr == 0) {
                     const u32 c = s + plen;
                     if (c > re0 + 33u && (u64)c + 31ull <= (u64)hi) {
                         const u32 idx = c - 32u + (u32)lane_id();
@@ -435,9 +546,7 @@ __global__ __launch_bounds__(64) void k1_split(const u8 *__restrict__ in, const 
                     }
                 }
                 // otherwise bracket around the last length
-                u32 nlo = 0, nhi = 0;
-                bool br = false;
-                if (!done && plen) {
+                if (!done && !br && plen) {
                     // as wide as the last prediction was wrong (x4), at least 1.5 % of the length
                     const u32 half = min(max(2048u, 4u * perr + plen / 64u), max(2048u, plen / 2u));
                     const u32 c = s + plen;
@@ -853,8 +962,16 @@ u32 run_chain(bz2hip_ctx *c, const u8 *d_in, u32 n, int level, const u32 *d_rs, 
     Batch &B = c->batch;
     {
         ProfScope ps(c, P_RLE1_SPLIT, 0);
-        k1_split<<<1, 64, 0, c->stream>>>(d_in, d_rs, d_P, c->w_P16, d_agg2, n, (u32)level * 100000u, max_blocks, d_starts, c->w_binfo,
-                                          B.ctl + 9, s0, stop);
+        // with more than a few blocks ahead, the brackets of all possible block ends first (parallel)
+        const u32 bs = (u32)level * 100000u;
+        const bool hints = c->w_hint && c->split_hints &&
+                           (c->split_hints > 1 || (u64)(std::min(stop, n) - std::min(s0, n)) > 8ull * bs);
+        if (hints) {
+            k1_hints<<<(n / K1_CELL + 1 + 255) / 256, 256, 0, c->stream>>>(d_P, c->w_P16, d_agg2, n, bs, c->w_hint);
+            KCHECK();
+        }
+        k1_split<<<1, 64, 0, c->stream>>>(d_in, d_rs, d_P, c->w_P16, d_agg2, n, bs, max_blocks, d_starts, c->w_binfo,
+                                          B.ctl + 9, s0, stop, hints ? c->w_hint : (const u32 *)nullptr);
         KCHECK();
     }
     u32 cnt = 0;

@@ -799,3 +799,39 @@ def test_block_starts_inside_long_runs(ctx, orc):
     for level in (1, 2):
         want, nb = orc.compress(d, level)
         assert ctx.compress(d, level) == want, level
+
+
+def test_split_hints_agree_with_the_search(orc):
+    """k1_hints brackets every block end before the chain walks (on by itself beyond 8 blocks; forced
+    here so that inputs the oracle splits in seconds use it): block starts must be the oracle's with
+    the table and without, on run-free data, long runs, a run-heavy region that follows a run-free
+    one (the wave's 128-cell window is too short there), and lengths on and off cell and tile edges."""
+    import bzip2_amd
+    rng = np.random.default_rng(77)
+    shapes = {
+        "random": rng.integers(0, 256, 1_500_000, dtype=np.uint8),
+        "text": corpus.text(1_200_000, 5),
+        "free_then_runs": np.concatenate((rng.integers(0, 256, 400_000, dtype=np.uint8),
+                                          np.repeat(rng.integers(0, 256, 9000, dtype=np.uint8), 255),
+                                          rng.integers(0, 256, 300_000, dtype=np.uint8))),
+        "runs_then_free": np.concatenate((np.repeat(rng.integers(0, 256, 40000, dtype=np.uint8),
+                                                    rng.integers(1, 90, 40000)),
+                                          corpus.text(500_000, 6))),
+        "short_runs": np.repeat(rng.integers(0, 256, 300_000, dtype=np.uint8), rng.integers(1, 7, 300_000)),
+        "zeros": np.zeros(6_000_000, dtype=np.uint8),
+        "cell_edge": rng.integers(0, 256, 256 * 4000, dtype=np.uint8),
+        "tile_edge": rng.integers(0, 4, 4096 * 300, dtype=np.uint8),
+        "one_over": rng.integers(0, 256, 4096 * 250 + 1, dtype=np.uint8),
+    }
+    want = {(k, lv): orc.split(d, lv) for k, d in shapes.items() for lv in (1, 2)}
+    for knob in ("2", "0"):
+        os.environ["BZ2HIP_SPLIT_HINTS"] = knob
+        try:
+            c = bzip2_amd.Context()
+        finally:
+            del os.environ["BZ2HIP_SPLIT_HINTS"]
+        try:
+            for (k, lv), w in want.items():
+                assert np.array_equal(c.split(shapes[k], lv), w), (knob, k, lv)
+        finally:
+            c.close()
