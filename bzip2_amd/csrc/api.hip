@@ -129,6 +129,7 @@ static void wfree(bz2hip_ctx *c) {
     c->w_P16 = nullptr;
     c->w_binfo = nullptr;
     c->w_hint = nullptr;
+    c->w_agg1r = c->w_agg2r = nullptr;
 }
 
 static u32 window_max_blocks(size_t wlen, int level) {
@@ -151,7 +152,8 @@ static size_t layout_window(bz2hip_ctx *c, size_t wlen, u32 mb, u8 *base) {
     u32 *a1 = A.get<u32>(tiles), *a2 = A.get<u32>(tiles), *st = A.get<u32>((size_t)mb + 8);
     u32 *bi = A.get<u32>(2 * ((size_t)mb + 8));
     u32 *hn = A.get<u32>(2 * cells);
-    if (base) { c->w_rs = rs; c->w_P = P; c->w_P16 = p16; c->w_binfo = bi; c->w_hint = hn; c->w_agg1 = a1; c->w_agg2 = a2; c->w_starts = st; }
+    u32 *a1r = A.get<u32>(tiles), *a2r = A.get<u32>(tiles);
+    if (base) { c->w_agg1r = a1r; c->w_agg2r = a2r; c->w_rs = rs; c->w_P = P; c->w_P16 = p16; c->w_binfo = bi; c->w_hint = hn; c->w_agg1 = a1; c->w_agg2 = a2; c->w_starts = st; }
     return A.off;
 }
 // per-batch CRC tile partials (the emit needs none since its tile offsets come from the scan)
@@ -616,7 +618,7 @@ extern "C" int bz2hip_compress_device_noalloc(bz2hip_ctx *c, const void *d_in, s
             Batch batch;
             u32 *w_rs, *w_P, *w_agg1, *w_agg2, *w_starts, *w_cagg;
             u16 *w_P16;
-            u32 *w_binfo, *w_hint;
+            u32 *w_binfo, *w_hint, *w_agg1r, *w_agg2r;
             size_t w_cap;
             u32 w_maxblocks, w_ETPB;
             int w_eagg_nb;
@@ -624,7 +626,7 @@ extern "C" int bz2hip_compress_device_noalloc(bz2hip_ctx *c, const void *d_in, s
             explicit Saved(bz2hip_ctx *cc)
                 : c(cc), batch(std::move(cc->batch)), w_rs(cc->w_rs), w_P(cc->w_P), w_agg1(cc->w_agg1),
                   w_agg2(cc->w_agg2), w_starts(cc->w_starts), w_cagg(cc->w_cagg),
-                  w_P16(cc->w_P16), w_binfo(cc->w_binfo), w_hint(cc->w_hint), w_cap(cc->w_cap), w_maxblocks(cc->w_maxblocks), w_ETPB(cc->w_ETPB),
+                  w_P16(cc->w_P16), w_binfo(cc->w_binfo), w_hint(cc->w_hint), w_agg1r(cc->w_agg1r), w_agg2r(cc->w_agg2r), w_cap(cc->w_cap), w_maxblocks(cc->w_maxblocks), w_ETPB(cc->w_ETPB),
                   w_eagg_nb(cc->w_eagg_nb), profile(cc->profile) {
                 cc->batch = Batch();
                 cc->fixed_ws = true;
@@ -637,6 +639,7 @@ extern "C" int bz2hip_compress_device_noalloc(bz2hip_ctx *c, const void *d_in, s
                 c->w_P16 = w_P16;
                 c->w_binfo = w_binfo;
                 c->w_hint = w_hint;
+                c->w_agg1r = w_agg1r; c->w_agg2r = w_agg2r;
                 c->w_cap = w_cap; c->w_maxblocks = w_maxblocks; c->w_ETPB = w_ETPB;
                 c->w_eagg_nb = w_eagg_nb;
                 c->profile = profile;

@@ -156,6 +156,7 @@ struct bz2hip_ctx {
     u32 *w_starts = nullptr;
     u32 *w_binfo = nullptr;  // per block: end of its first run, P just after it (k1_split -> k1_emit)
     u16 *w_P16 = nullptr;    // flushed-length prefix per input byte, tile-local (k1_rle1.hip)
+    u32 *w_agg1r = nullptr, *w_agg2r = nullptr; // tile aggregates as produced (k1_scan_tiles reads these, writes w_agg1 / w_agg2)
     u32 *w_hint = nullptr;   // per 256-byte cell: bracket of the end of a block that starts there (k1_hints)
     u32 *w_cagg = nullptr;   // CRC tile partials [batch blocks][w_ETPB] (used on the other stream)
     void *w_region = nullptr;  // device region holding rs / P / aggregates / starts

@@ -48,38 +48,44 @@ __global__ __launch_bounds__(256) void k1_heads_p1(const u8 *__restrict__ in, u3
     if (threadIdx.x == 0) agg[tile] = t;
 }
 
-// exclusive scans over a flat array of tile aggregates (single workgroup of 1024), tiles
-// [first, count): the carry of the tiles before `first` comes in through *total_out (input chunks
-// are scanned as they arrive), and the running total goes back there
+// exclusive scans over a flat array of tile aggregates, tiles [first, count), 1024 tiles per
+// workgroup.  Out of place (raw -> out), so a workgroup takes its carry from a reduction of the
+// raw values before its tiles (at most 64 coalesced loads per thread for 256 MiB of input) instead
+// of waiting for the workgroups before it; input chunks are scanned as they arrive, each launch
+// reducing from tile 0.  The workgroup that holds the last tile leaves the running total.
 template <bool MAXOP>
-__global__ __launch_bounds__(1024) void k1_scan_tiles(u32 *__restrict__ agg, u32 first, u32 count,
-                                                      u32 *__restrict__ total_out) {
+__global__ __launch_bounds__(1024) void k1_scan_tiles(const u32 *__restrict__ raw, u32 *__restrict__ out,
+                                                      u32 first, u32 count, u32 *__restrict__ total_out) {
     __shared__ u32 sm[20];
-    u32 carry = (first && total_out) ? *total_out : 0;
-    __syncthreads();
-    for (u32 t0 = first; t0 < count; t0 += 1024) {
-        u32 t = t0 + threadIdx.x;
-        u32 v = (t < count) ? agg[t] : 0;
-        u32 tot, ex;
-        if (MAXOP) {
-            u32 inc = block_incl_scan_max<1024>(v, sm, &tot);
-            u32 prev = __shfl_up(inc, 1, 64);
-            if (lane_id() == 0) {
-                ex = 0;
-                for (int q = 0; q < wave_id(); q++) ex = max(ex, sm[q]);
-            } else {
-                ex = prev;
-            }
-            ex = max(ex, carry);
-            carry = max(carry, tot);
-        } else {
-            ex = carry + block_excl_scan_add<1024>(v, sm, &tot);
-            carry += tot;
-        }
-        if (t < count) agg[t] = ex;
-        __syncthreads();
+    const u32 t0 = first + blockIdx.x * 1024u;
+    u32 acc = 0;
+#pragma unroll 8
+    for (u32 q = threadIdx.x; q < t0; q += 1024u) {
+        const u32 v = raw[q];
+        acc = MAXOP ? max(acc, v) : acc + v;
     }
-    if (threadIdx.x == 0 && total_out) *total_out = carry;
+    const u32 carry = MAXOP ? block_reduce_max<1024>(acc, sm) : block_reduce_add<1024>(acc, sm);
+    __syncthreads();
+    const u32 t = t0 + threadIdx.x;
+    const u32 v = (t < count) ? raw[t] : 0;
+    u32 tot, ex;
+    if (MAXOP) {
+        const u32 inc = block_incl_scan_max<1024>(v, sm, &tot);
+        const u32 prev = __shfl_up(inc, 1, 64);
+        if (lane_id() == 0) {
+            ex = 0;
+            for (int q = 0; q < wave_id(); q++) ex = max(ex, sm[q]);
+        } else {
+            ex = prev;
+        }
+        ex = max(ex, carry);
+        tot = max(tot, carry);
+    } else {
+        ex = carry + block_excl_scan_add<1024>(v, sm, &tot);
+        tot += carry;
+    }
+    if (t < count) out[t] = ex;
+    if (threadIdx.x == 0 && total_out && t0 + 1024u >= count) *total_out = tot;
 }
 
 // The flushed-length prefix P and the run starts are kept per CELL of 256 input bytes, not per
@@ -939,15 +945,15 @@ void run_scan(bz2hip_ctx *c, const u8 *d_in, u32 n, u32 *d_rs, u32 *d_P, u32 *d_
         // n is passed as the bytes present so far: the last tile of a chunk clamps at its end, and
         // chunks are multiples of the tile, so every tile sees exactly its own bytes
         const u32 upto = (u32)(off + len);
-        k1_heads_p1<<<t1 - t0, 256, 0, c->stream>>>(d_in, upto, d_agg1, t0);
+        k1_heads_p1<<<t1 - t0, 256, 0, c->stream>>>(d_in, upto, c->w_agg1r, t0);
         KCHECK();
-        k1_scan_tiles<true><<<1, 1024, 0, c->stream>>>(d_agg1, t0, t1, carry_max);
+        k1_scan_tiles<true><<<(t1 - t0 + 1023) / 1024, 1024, 0, c->stream>>>(c->w_agg1r, d_agg1, t0, t1, carry_max);
         KCHECK();
-        k1_cells<<<t1 - t0, 256, 0, c->stream>>>(d_in, upto, d_agg1, d_rs, d_agg2, d_P, c->w_P16, t0);
+        k1_cells<<<t1 - t0, 256, 0, c->stream>>>(d_in, upto, d_agg1, d_rs, c->w_agg2r, d_P, c->w_P16, t0);
         KCHECK();
     }
     c->up.active = false;
-    k1_scan_tiles<false><<<1, 1024, 0, c->stream>>>(d_agg2, 0, tiles, B.ctl + 8);
+    k1_scan_tiles<false><<<std::max(1u, (tiles + 1023) / 1024), 1024, 0, c->stream>>>(c->w_agg2r, d_agg2, 0, tiles, B.ctl + 8);
     KCHECK();
     k1_sentinels<<<1, 64, 0, c->stream>>>(d_rs, d_P, c->w_P16, d_agg2, carry_max, n, B.ctl + 8);
     KCHECK();
