@@ -517,7 +517,66 @@ __global__ __launch_bounds__(64) void k3_mtf_compose(const u32 *__restrict__ nAr
 __device__ __forceinline__ u32 ndigits(u32 r) { return 31u - __clz(r + 1u); } // floor(log2(r+1))
 
 // element j in [0, n]: j == n is the virtual EOB (non-zero)
-// phase 1: tile summary {lz, tz, inner, allzero}
+// Both tile kernels give every thread 16 consecutive elements (one 16-byte load) and walk them in
+// registers with "position after the last non-zero" as the only state; what enters a thread is a
+// max-scan over the threads before it.  (A row of 64 elements per wave step cost 86 vector
+// instructions per row in the emit kernel, which made it issue-bound: 0.45 ms for 0.5 GB.)
+struct R2Lane {
+    u32 w[4]; // the 16 positions
+    u32 nz;   // bit k: element k is non-zero (the EOB counts, elements past it do not)
+};
+__device__ __forceinline__ void r2_load(const u8 *__restrict__ mp, u32 tbase, u32 n, R2Lane &L) {
+    // the slot is padded to whole tiles and 16-byte aligned
+    const uint4 v = *(const uint4 *)(mp + tbase);
+    L.w[0] = v.x; L.w[1] = v.y; L.w[2] = v.z; L.w[3] = v.w;
+    u32 nz = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        // a byte's bits folded onto its bit 0, the four bit-0s gathered by one multiplication
+        u32 t = L.w[q] | (L.w[q] >> 4);
+        t |= t >> 2;
+        t |= t >> 1;
+        nz |= (((t & 0x01010101u) * 0x01020408u) >> 24 & 15u) << (4 * q);
+    }
+    if (n < tbase + 16u) { // the EOB at n (non-zero) and nothing after it
+        if (n >= tbase) nz = (nz & ((1u << (n - tbase)) - 1u)) | (1u << (n - tbase));
+        else nz = 0;
+    }
+    L.nz = nz;
+}
+// position after the last non-zero before this thread inside the tile (0 = none), and the tile's
+// per-wave last / first non-zero through wl / wf
+__device__ __forceinline__ u32 r2_prev(const R2Lane &L, u32 tbase, u32 *wl, u32 *wf) {
+    const int w = wave_id(), lane = lane_id();
+    const u32 lastp1 = L.nz ? tbase + 32u - (u32)__clz(L.nz) : 0u;
+    const u32 firstp = L.nz ? tbase + (u32)__ffs(L.nz) - 1u : 0xffffffffu;
+    const u32 inc = wave_incl_scan_max(lastp1);
+    const u32 fmin = ~wave_reduce_max(~firstp);
+    if (lane == 63) wl[w] = inc;
+    if (lane == 0) wf[w] = fmin;
+    __syncthreads();
+    u32 prevp1 = 0;
+    for (int q = 0; q < w; q++) prevp1 = max(prevp1, wl[q]);
+    const u32 up = __shfl_up(inc, 1, 64);
+    if (lane > 0) prevp1 = max(prevp1, up);
+    return prevp1;
+}
+// symbols the thread's elements emit when the last non-zero before them ended at prev (position + 1)
+__device__ __forceinline__ u32 r2_count(const R2Lane &L, u32 tbase, u32 prev) {
+    u32 cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const bool nz = (L.nz >> k) & 1u;
+        const u32 j = tbase + (u32)k;
+        const u32 e = 1u + ndigits(j - prev);
+        cnt += nz ? e : 0u;
+        prev = nz ? j + 1u : prev;
+    }
+    return cnt;
+}
+
+// phase 1: tile summary {lz, tz, inner, allzero}; inner leaves out the run digits before the
+// tile's first non-zero (that run may have begun in an earlier tile: phase 2 adds them)
 __global__ __launch_bounds__(256) void k3_rle2_p1(const u8 *__restrict__ mtfpos,
                                                   const u32 *__restrict__ nArr,
                                                   u32 *__restrict__ r2agg, u32 S, u32 TPB) {
@@ -526,64 +585,27 @@ __global__ __launch_bounds__(256) void k3_rle2_p1(const u8 *__restrict__ mtfpos,
     const u32 base = blockIdx.x * R2TILE;
     if (base > n) return;
     const u32 end = min(base + R2TILE, n + 1);
-    const int w = wave_id(), lane = lane_id();
-    __shared__ u32 wfirst[4], wlast[4], winner[4];
-    const u8 *mp = mtfpos + (size_t)b * S;
-    // per wave: rows of 64 elements in its 1024-element range
-    u32 first = 0xffffffffu, last = 0; // position+1 of last non-zero seen (0 = none)
-    u32 inner = 0;
-    // the slot is padded to whole tiles: 16 unconditional loads in flight
-    u8 pv[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) pv[k] = mp[base + w * 1024 + k * 64 + lane];
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        u32 rowbase = base + w * 1024 + k * 64;
-        u32 j = rowbase + lane;
-        bool nz = (j < end) && (j == n || pv[k] != 0);
-        u64 m = __ballot(nz);
-        if (m == 0) continue;
-        // previous non-zero for this lane: inside row, else `last`
-        u64 below = m & ((1ull << lane) - 1ull);
-        u32 prevp1 = below ? (rowbase + (63 - __clzll((unsigned long long)below)) + 1) : last;
-        if (nz) {
-            u32 e = 1;
-            if (prevp1 != 0) { // previous non-zero known inside this wave's range
-                u32 r = j - prevp1;
-                if (r > 0) e += ndigits(r);
-            }
-            inner += e;
-        }
-        if (first == 0xffffffffu) first = rowbase + (__ffsll((unsigned long long)m) - 1);
-        last = rowbase + (63 - __clzll((unsigned long long)m)) + 1;
-    }
-    inner = wave_reduce_add(inner);
-    if (lane == 0) {
-        wfirst[w] = first;
-        wlast[w] = last;
-        winner[w] = inner;
-    }
+    __shared__ u32 wl[4], wf[4], ws[4];
+    const u32 tbase = base + threadIdx.x * 16u;
+    R2Lane L;
+    r2_load(mtfpos + (size_t)b * S, tbase, n, L);
+    const u32 prevp1 = r2_prev(L, tbase, wl, wf);
+    // the tile's first non-zero counts as if no zero preceded it
+    const u32 cnt = r2_count(L, tbase, prevp1 ? prevp1 : tbase + (u32)__ffs(L.nz) - 1u);
+    const u32 wsum = wave_reduce_add(cnt);
+    if (lane_id() == 0) ws[wave_id()] = wsum;
     __syncthreads();
     if (threadIdx.x == 0) {
-        // stitch the 4 wave ranges: a wave's first non-zero whose run started in an earlier wave
-        u32 tot = 0, tl = 0, tf = 0xffffffffu;
-        for (int q = 0; q < 4; q++) {
-            tot += winner[q];
-            if (wfirst[q] != 0xffffffffu) {
-                if (tl != 0) {
-                    u32 r = wfirst[q] - tl;
-                    if (r > 0) tot += ndigits(r);
-                }
-                if (tf == 0xffffffffu) tf = wfirst[q];
-                tl = wlast[q];
-            }
-        }
-        u32 cnt = end - base;
-        u32 az = (tf == 0xffffffffu) ? 1u : 0u;
-        u32 lz = az ? cnt : (tf - base);
-        u32 tz = az ? cnt : (end - tl);
+        const u32 tot = ws[0] + ws[1] + ws[2] + ws[3];
+        const u32 tl = max(max(wl[0], wl[1]), max(wl[2], wl[3]));
+        const u32 tf = min(min(wf[0], wf[1]), min(wf[2], wf[3]));
+        const u32 cnt_t = end - base;
+        const u32 az = (tf == 0xffffffffu) ? 1u : 0u;
         u32 *o = r2agg + ((size_t)b * TPB + blockIdx.x) * 4;
-        o[0] = lz; o[1] = tz; o[2] = tot; o[3] = az;
+        o[0] = az ? cnt_t : (tf - base);
+        o[1] = az ? cnt_t : (end - tl);
+        o[2] = tot;
+        o[3] = az;
     }
 }
 
@@ -630,7 +652,8 @@ __global__ __launch_bounds__(256) void k3_rle2_p2(const u32 *__restrict__ nArr,
     }
 }
 
-// phase 3: write symbols + frequencies
+// phase 3: write symbols + frequencies.  The tile's symbols are put together in LDS (every thread
+// at its own offset) and leave in coalesced 2-byte rows.
 __global__ __launch_bounds__(256) void k3_rle2_p3(const u8 *__restrict__ mtfpos,
                                                   const u32 *__restrict__ nArr,
                                                   const u32 *__restrict__ r2agg,
@@ -641,103 +664,56 @@ __global__ __launch_bounds__(256) void k3_rle2_p3(const u8 *__restrict__ mtfpos,
     const u32 n = nArr[b];
     const u32 base = blockIdx.x * R2TILE;
     if (base > n) return;
-    const u32 end = min(base + R2TILE, n + 1);
-    const int w = wave_id(), lane = lane_id();
-    __shared__ u32 wfirst[4], wlast[4], wsum[4];
+    __shared__ u32 wl[4], wf[4], sm[8];
     // every counter four times (lane mod 4): RUNA, RUNB and the first positions are most of the symbols,
     // and lanes of one LDS atomic that meet on a word are served one by one
     __shared__ u32 hist[264 * 4];
+    // symbols of the tile: at most one per element, plus the digits of a run that came in (< 20)
+    __shared__ u16 sbuf[R2TILE + 32];
     for (u32 i = threadIdx.x; i < 264 * 4; i += 256) hist[i] = 0;
     u32 *const myhist = hist + (threadIdx.x & 3u);
-    const u8 *mp = mtfpos + (size_t)b * S;
     const u32 *ag = r2agg + ((size_t)b * TPB + blockIdx.x) * 4;
     const u32 tile_off = ag[0], carry_in = ag[1];
     const u32 eob = alpha[b] - 1;
-    // pass A: per wave first/last non-zero
-    u64 hm[16];
-    u32 myv[16];
-    u32 first = 0xffffffffu, last = 0;
-    u8 pv[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) pv[k] = mp[base + w * 1024 + k * 64 + lane];
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        u32 rowbase = base + w * 1024 + k * 64;
-        u32 j = rowbase + lane;
-        u32 v = 0;
-        if (j < end) v = (j == n) ? 0xffffu : pv[k];
-        myv[k] = v;
-        u64 m = __ballot(v != 0);
-        hm[k] = m;
-        if (m) {
-            if (first == 0xffffffffu) first = rowbase + (__ffsll((unsigned long long)m) - 1);
-            last = rowbase + (63 - __clzll((unsigned long long)m)) + 1;
-        }
-    }
-    if (lane == 0) {
-        wfirst[w] = first;
-        wlast[w] = last;
-    }
-    __syncthreads();
-    // previous non-zero (+1) before this wave's range inside the tile; 0 = none in tile
-    u32 prev_in_tile = 0;
-    for (int q = 0; q < w; q++)
-        if (wlast[q]) prev_in_tile = wlast[q];
-    // pass B: emit counts per element, wave-level sums
-    u32 ecnt[16];
-    u32 runlen[16];
-    u32 lastp1 = prev_in_tile;
-    u32 wtotal = 0;
+    const u32 tbase = base + threadIdx.x * 16u;
+    R2Lane L;
+    r2_load(mtfpos + (size_t)b * S, tbase, n, L);
+    const u32 prevp1 = r2_prev(L, tbase, wl, wf);
+    // nothing non-zero before this thread in the tile: the run reaches the tile start and carry_in
+    // zeros beyond it (prev may wrap below zero: only differences are used)
+    u32 prev = prevp1 ? prevp1 : base - carry_in;
+    const u32 cnt = r2_count(L, tbase, prev);
+    u32 total;
+    u32 o = block_excl_scan_add<256>(cnt, sm, &total);
+    u32 runa = 0, runb = 0;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        u32 rowbase = base + w * 1024 + k * 64;
-        u32 j = rowbase + lane;
-        u64 m = hm[k];
-        u32 e = 0, r = 0;
-        if (m) {
-            u64 below = m & ((1ull << lane) - 1ull);
-            u32 prevp1 = below ? (rowbase + (63 - __clzll((unsigned long long)below)) + 1) : lastp1;
-            if (myv[k] != 0) {
-                if (prevp1 != 0) r = j - prevp1;
-                else r = carry_in + (j - base); // run reaches the tile start
-                e = 1 + (r > 0 ? ndigits(r) : 0u);
-            }
-            lastp1 = rowbase + (63 - __clzll((unsigned long long)m)) + 1;
-        }
-        ecnt[k] = e;
-        runlen[k] = r;
-        wtotal += e;
-    }
-    wtotal = wave_reduce_add(wtotal);
-    if (lane == 0) wsum[w] = wtotal;
-    __syncthreads();
-    u32 run = tile_off;
-    for (int q = 0; q < w; q++) run += wsum[q];
-    u16 *out = mtf + (size_t)b * S2;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        u32 e = ecnt[k];
-        u32 inc = wave_incl_scan_add(e);
-        u32 o = run + inc - e;
-        run += __shfl(inc, 63, 64);
-        if (e) {
-            u32 r = runlen[k];
+        if ((L.nz >> k) & 1u) {
+            const u32 j = tbase + (u32)k;
+            const u32 r = j - prev;
+            prev = j + 1u;
             if (r > 0) { // java:83-99
                 u32 rep = r - 1;
                 for (;;) {
-                    u32 dgt = rep & 1u;
-                    out[o++] = (u16)dgt;
-                    atomicAdd(&myhist[dgt * 4u], 1u);
+                    const u32 dgt = rep & 1u;
+                    sbuf[o++] = (u16)dgt;
+                    runb += dgt;
+                    runa += dgt ^ 1u;
                     if (rep <= 1) break;
                     rep = (rep - 2) >> 1;
                 }
             }
-            u32 sym = (myv[k] == 0xffffu) ? eob : (myv[k] + 1);
-            out[o] = (u16)sym;
+            const u32 v = (L.w[k >> 2] >> (8 * (k & 3))) & 255u;
+            const u32 sym = (j == n) ? eob : (v + 1u);
+            sbuf[o++] = (u16)sym;
             atomicAdd(&myhist[sym * 4u], 1u);
         }
     }
+    if (runa) atomicAdd(&myhist[0], runa);
+    if (runb) atomicAdd(&myhist[4], runb);
     __syncthreads();
+    u16 *out = mtf + (size_t)b * S2 + tile_off;
+    for (u32 q = threadIdx.x; q < total; q += 256) out[q] = sbuf[q];
     for (u32 i = threadIdx.x; i < 264; i += 256) {
         u32 c = hist[i * 4] + hist[i * 4 + 1] + hist[i * 4 + 2] + hist[i * 4 + 3];
         if (c) atomicAdd(&freq[b * 264 + i], c);
