@@ -102,7 +102,16 @@ __global__ __launch_bounds__(256) void k4_select(const u16 *__restrict__ mtf,
             const u32 lbase = threadIdx.x * GROUP;
             const u32 cnt = min((u32)GROUP, L - g * GROUP);
             u64 cost = 0;
-            for (u32 i = 0; i < cnt; i++) cost += plen[st16[lbase + i]];
+            u32 sw[GROUP / 2]; // a whole group: its 25 words and their 50 length words are read in two batches
+            const bool whole = cnt == (u32)GROUP;
+            if (whole) {
+#pragma unroll
+                for (int i = 0; i < GROUP / 2; i++) sw[i] = stage[threadIdx.x * (GROUP / 2) + i];
+#pragma unroll
+                for (int i = 0; i < GROUP / 2; i++) cost += plen[sw[i] & 0xffffu] + plen[sw[i] >> 16];
+            } else {
+                for (u32 i = 0; i < cnt; i++) cost += plen[st16[lbase + i]];
+            }
             int best = 0;
             u32 bestc = (u32)(cost & 1023u);
             for (int t = 1; t < tables; t++) {
@@ -114,14 +123,27 @@ __global__ __launch_bounds__(256) void k4_select(const u16 *__restrict__ mtf,
             }
             u32 *const hb = &hist[(u32)best * HL * HSR + hr];
             u32 prev = st16[lbase], run = 1; // cnt >= 1; equal neighbours are added at once
-            for (u32 i = 1; i < cnt; i++) {
-                const u32 sy = st16[lbase + i];
-                if (sy != prev) {
-                    atomicAdd(&hb[prev * HSR], run);
-                    prev = sy;
-                    run = 0;
+            if (whole) {
+#pragma unroll
+                for (int i = 1; i < GROUP; i++) {
+                    const u32 sy = (i & 1) ? (sw[i >> 1] >> 16) : (sw[i >> 1] & 0xffffu);
+                    if (sy != prev) {
+                        atomicAdd(&hb[prev * HSR], run);
+                        prev = sy;
+                        run = 0;
+                    }
+                    run++;
                 }
-                run++;
+            } else {
+                for (u32 i = 1; i < cnt; i++) {
+                    const u32 sy = st16[lbase + i];
+                    if (sy != prev) {
+                        atomicAdd(&hb[prev * HSR], run);
+                        prev = sy;
+                        run = 0;
+                    }
+                    run++;
+                }
             }
             atomicAdd(&hb[prev * HSR], run);
             if (store) sel[(size_t)b * SEL_STRIDE + g] = (u8)best;
