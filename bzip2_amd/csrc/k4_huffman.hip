@@ -155,6 +155,19 @@ __global__ __launch_bounds__(256) void k4_select(const u16 *__restrict__ mtf,
         out[q] = hist[q * HSR] + hist[q * HSR + 1] + hist[q * HSR + 2] + hist[q * HSR + 3];
 }
 
+#ifdef EXP_TIMING
+__device__ unsigned long long g_k4phase[8];
+extern "C" void bz2hip_debug_k4(unsigned long long *out) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k4phase), sizeof(unsigned long long) * 8);
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_k4phase), z, sizeof(z));
+}
+#define K4_MARK(k) do { if (threadIdx.x == 0) { unsigned long long t_ = wall_clock64(); atomicAdd(&g_k4phase[k], t_ - k4_t); k4_t = t_; } } while (0)
+#define K4_INIT unsigned long long k4_t = wall_clock64();
+#else
+#define K4_MARK(k)
+#define K4_INIT
+#endif
 // ------------------------------------------------------------------ allocator (single lane)
 // S/BZip2HuffmanAllocator.swift:44-66
 // a[i] % len for a parent pointer: the pointers are `tail` or `tail + len` with tail < len, so one
@@ -182,26 +195,52 @@ __device__ int ha_first(const int *a, int len, int i, int nodes_to_move) {
 }
 
 // S/BZip2HuffmanAllocator.swift:197-223 with :72-104, :112-122, :128-147, :155-189
+#ifdef EXP_TIMING
+#define K4A_MARK(k) do { unsigned long long t_ = wall_clock64(); atomicAdd(&g_k4phase[k], t_ - k4a_t); k4a_t = t_; } while (0)
+#define K4A_INIT k4a_t = wall_clock64();
+#else
+#define K4A_MARK(k)
+#define K4A_INIT
+#endif
 __device__ void ha_allocate(int *a, int len, int max_len) {
+#ifdef EXP_TIMING
+    unsigned long long k4a_t = 0;
+#endif
     if (len == 2) { a[1] = 1; a[0] = 1; return; }
     if (len == 1) { a[0] = 1; return; }
     {   // setExtendedParentPointers
+        K4A_INIT
         a[0] += a[1];
         int head = 0, tail = 1, top = 2;
+        // One LDS round trip per merge: the two candidates of either queue are read together, the two
+        // picks are selects on registers (as written in the reference, every pick is a dependent read
+        // behind a branch: four round trips and eight branches per merge on one lane).  Reads past the
+        // picks' guards (a[top], a[top + 1] with top >= len; a[head + 1] == a[tail]) land inside the
+        // array and are not used.
         while (tail < len - 1) {
-            int temp;
-            if (top >= len || a[head] < a[top]) { temp = a[head]; a[head++] = tail; }
-            else                                { temp = a[top++]; }
-            if (top >= len || (head < tail && a[head] < a[top])) { temp += a[head]; a[head++] = tail + len; }
-            else                                                 { temp += a[top++]; }
+            const int hv0 = a[head], hv1 = a[head + 1];
+            const int tv0 = a[top], tv1 = a[top + 1];
+            const bool c1 = (top >= len) | (hv0 < tv0);
+            int temp = c1 ? hv0 : tv0;
+            if (c1) a[head] = tail;
+            const int nh = c1 ? hv1 : hv0, nt = c1 ? tv0 : tv1;
+            head += c1 ? 1 : 0;
+            top += c1 ? 0 : 1;
+            const bool c2 = (top >= len) | ((head < tail) & (nh < nt));
+            temp += c2 ? nh : nt;
+            if (c2) a[head] = tail + len;
+            head += c2 ? 1 : 0;
+            top += c2 ? 0 : 1;
             a[tail++] = temp;
         }
+        K4A_MARK(4);
     }
     int r;
     {   // findNodesToRelocate
         int node = len - 2;
         for (int depth = 1; depth < max_len - 1 && node > 1; depth++) node = ha_first(a, len, node - 1, 0);
         r = node;
+        K4A_MARK(5);
     }
     if (ha_mod(a[0], len) >= r) {
         int first_node = len - 2, next_node = len - 1;
@@ -250,15 +289,23 @@ __global__ __launch_bounds__(256) void k4_lengths(const u32 *__restrict__ mtflen
     __shared__ int key[HL];
     __shared__ int sorted[HL];
     __shared__ int a[HL];
+    K4_INIT
     for (int j = threadIdx.x; j < HL; j += 256) {
         u32 f = 0;
-        if (j < alpha)
-            for (u32 p = 0; p < parts; p++)
-                f += hpart[(((size_t)b * HS_PART_MAX + p) * MAX_TABLES + t) * HL + j];
+        if (j < alpha) {
+            // all parts requested at once (a loop to `parts` waits for every load in turn)
+            u32 v[HS_PART_MAX];
+#pragma unroll
+            for (u32 p = 0; p < HS_PART_MAX; p++)
+                v[p] = hpart[(((size_t)b * HS_PART_MAX + min(p, parts - 1u)) * MAX_TABLES + t) * HL + j];
+#pragma unroll
+            for (u32 p = 0; p < HS_PART_MAX; p++) f += p < parts ? v[p] : 0u;
+        }
         hfreq[((size_t)b * MAX_TABLES + t) * HL + j] = f;
         key[j] = (int)((f << 9) | (u32)j);
     }
     __syncthreads();
+    K4_MARK(0);
     for (int j = threadIdx.x; j < alpha; j += 256) {
         int kj = key[j];
         int rnk = 0;
@@ -271,12 +318,15 @@ __global__ __launch_bounds__(256) void k4_lengths(const u32 *__restrict__ mtflen
     // give their slots to the next tables (2600 level-1 blocks are 15 600 tables: the kernel is bound by
     // how many of these workgroups a CU holds, not by the allocator's latency).
     if (wave_id() != 0) return;
+    K4_MARK(1);
     if (threadIdx.x == 0) ha_allocate(a, alpha, 20);
+    K4_MARK(2);
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
     for (int i = threadIdx.x; i < alpha; i += 64)
         hlen[((size_t)b * MAX_TABLES + t) * HL + (sorted[i] & 0x1ff)] = (u8)a[i];
+    K4_MARK(3);
 }
 
 // ------------------------------------------------------------------ canonical codes (:254-287)
