@@ -256,6 +256,36 @@ __device__ __forceinline__ u64 r0_key(const R0Tile &L, u32 local, u32 i, u32 d0,
     return (kk << KEY_SHIFT) | (u64)i;
 }
 
+// The key's low 24 bits alone (the first pass's histogram needs only its lowest digit): the same
+// sum of products modulo 2^24, every step one 24-bit multiply-add instead of 64-bit arithmetic.
+__device__ __forceinline__ u32 r0_key_low24(const R0Tile &L, u32 local, u32 d0, u32 xb) {
+    const u32 uniq = L.uniq;
+    u32 k, nxt;
+    if (d0 >= 4u && d0 <= 7u) {
+        const u32 *t32 = (const u32 *)L.t;
+        const u32 w = local >> 2, a = local & 3u;
+        const u32 w0 = t32[w], w1 = t32[w + 1], w2 = t32[w + 2];
+        const u32 lo = __builtin_amdgcn_alignbyte(w1, w0, a), hi = __builtin_amdgcn_alignbyte(w2, w1, a);
+        k = lo & 255u;
+        k = __umul24(k, uniq) + ((lo >> 8) & 255u);
+        k = __umul24(k, uniq) + ((lo >> 16) & 255u);
+        k = __umul24(k, uniq) + (lo >> 24);
+        u32 h = hi;
+        for (u32 q = 4; q < d0; q++) {
+            k = __umul24(k, uniq) + (h & 255u);
+            h >>= 8;
+        }
+        nxt = h & 255u;
+    } else {
+        k = 0;
+        for (u32 q = 0; q < d0; q++) k = __umul24(k, uniq) + L.t[local + q];
+        nxt = L.t[local + d0];
+    }
+    const u32 B = xb & 255u;
+    if (B > 1u) k = __umul24(k, B) + ((nxt * (xb >> 8)) >> 16);
+    return k;
+}
+
 // ------------------------------------------------------------------ LSD radix pass (u64 words)
 // DB = digit bits (8 or 10), RB = bins.  Per pass: tile digit histogram -> per-block scan -> stable
 // scatter.  The scatter first orders the tile by digit in LDS (rank = bin start + wave offset +
@@ -304,8 +334,8 @@ __global__ __launch_bounds__(RT_THREADS) void k2_radix_hist(const u64 *__restric
 #pragma unroll 4
         for (int k = 0; k < RT_ITEMS; k++) {
             const u32 local = k * RT_THREADS + threadIdx.x;
-            if (base + local < n)
-                atomicAdd(&hist[((u32)(r0_key(L, local, base + local, d0, xb) >> shift) & (RB - 1u)) * HR + hr], 1u);
+            if (base + local < n) // (this kernel builds keys only for the first pass: shift == KEY_SHIFT, DB <= 24)
+                atomicAdd(&hist[(r0_key_low24(L, local, d0, xb) & (RB - 1u)) * HR + hr], 1u);
         }
         flush();
         return;

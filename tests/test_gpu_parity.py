@@ -675,7 +675,11 @@ def test_multi_device_context(orc):
         try:
             assert c.compress(d3, 3) == want3, devices
             assert c.last_stats()["blocks"] >= 15
-            assert c.compress(d9, 9) == want9, devices
+            got9 = c.compress(d9, 9)
+            if got9 != want9 and os.path.isdir("gpurun_out"):  # flake hunt: keep the stream for a post-mortem
+                open("gpurun_out/md_fail_got.bin", "wb").write(got9)
+                open("gpurun_out/md_fail_info.txt", "w").write(repr((devices, c.last_stats())))
+            assert got9 == want9, devices
             assert c.compress(d3[:1000], 3) == orc.compress(d3[:1000], 3)[0]   # below the sharding threshold
             assert c.compress(b"", 3) == bytes.fromhex("425a683317724538509000000000")
             # streaming through the same device list, ragged writes
