@@ -593,18 +593,23 @@ __global__ __launch_bounds__(64) void k1_split(const u8 *__restrict__ in, const 
 struct EmitLane {
     u32 w[4];      // the 16 bytes
     u32 heads;     // bit j: byte j starts a run (inside [s, e))
-    u32 nxt;       // the byte after the 16
-    u32 r0;        // start of the run that enters byte 0 (>= s)
+    u32 lit;       // bit j: byte j is emitted as itself (the first four of a 255-chunk)
+    u32 cnt;       // bit j: a count byte follows byte j (its chunk ends there with >= 4 bytes)
+    u32 kprev;     // chunk phase of the byte before the 16: (its distance from the run start) mod 255
 };
 
-// loads and head detection; returns the thread's emitted-byte count
+// Loads, head detection and the emit decisions of the thread's 16 bytes as bit masks; returns the
+// thread's emitted-byte count.  EDGE = the tile holds the block's first or last byte (bounds are
+// tested per byte); an inner tile lies wholly inside (s, e) with at least one byte of the block
+// behind it, so every test against s and e is dropped.
+template <bool EDGE>
 __device__ __forceinline__ u32 emit_lane(const u8 *__restrict__ in, const u32 *__restrict__ agg_head,
                                          u32 s, u32 e, u32 gt, u32 *sm /* 8 words */, EmitLane &L) {
     const int lane = lane_id(), wv = wave_id();
     const u32 pos = gt * K1_TILE + threadIdx.x * 16u;
     // the 16 bytes: one aligned 16-byte load when they all lie below e (bytes before s belong to
     // the window too), single bytes at the block's end and for an unaligned input
-    if (pos + 16u <= e && (((uintptr_t)(in + pos)) & 15u) == 0) {
+    if ((!EDGE || pos + 16u <= e) && (((uintptr_t)(in + pos)) & 15u) == 0) {
         const uint4 v = *(const uint4 *)(in + pos);
         L.w[0] = v.x; L.w[1] = v.y; L.w[2] = v.z; L.w[3] = v.w;
     } else {
@@ -614,7 +619,7 @@ __device__ __forceinline__ u32 emit_lane(const u8 *__restrict__ in, const u32 *_
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const u32 i = pos + q * 4 + j;
-                if (i < e) x |= (u32)in[i] << (8 * j);
+                if (!EDGE || i < e) x |= (u32)in[i] << (8 * j);
             }
             L.w[q] = x;
         }
@@ -622,16 +627,23 @@ __device__ __forceinline__ u32 emit_lane(const u8 *__restrict__ in, const u32 *_
     // neighbours: last byte of the thread before, first byte of the thread after
     u32 prv = __shfl_up(L.w[3] >> 24, 1, 64);
     u32 nxt = __shfl_down(L.w[0] & 255u, 1, 64);
-    if (lane == 0 && pos > s && pos < e) prv = in[pos - 1];
-    if (lane == 63 && pos + 16u < e) nxt = in[pos + 16u];
-    L.nxt = nxt;
-    u32 heads = 0, lastp1 = 0;
+    if (lane == 0 && (!EDGE || (pos > s && pos < e))) prv = in[pos - 1];
+    if (lane == 63 && (!EDGE || pos + 16u < e)) nxt = in[pos + 16u];
+    u32 heads = 0, lastp1 = 0, valid = 0xffffu;
     u32 pb = prv;
+    if (EDGE) valid = 0;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         const u32 i = pos + j;
         const u32 c = (L.w[j >> 2] >> (8 * (j & 3))) & 255u;
-        const bool h = i >= s && i < e && (i == s || c != pb);
+        bool h;
+        if (EDGE) {
+            const bool in_blk = i >= s && i < e;
+            valid |= in_blk ? 1u << j : 0u;
+            h = in_blk && (i == s || c != pb);
+        } else {
+            h = c != pb;
+        }
         if (h) {
             heads |= 1u << j;
             lastp1 = i + 1;
@@ -643,27 +655,28 @@ __device__ __forceinline__ u32 emit_lane(const u8 *__restrict__ in, const u32 *_
     const u32 inc = wave_incl_scan_max(lastp1);
     if (lane == 63) sm[wv] = inc;
     __syncthreads();
-    u32 carry = max(agg_head[gt], s + 1u);
+    u32 carry = max(agg_head[gt], s + 1u); // (a run that straddles s is cut there: s is a head whatever the bytes say)
     for (int q = 0; q < wv; q++) carry = max(carry, sm[q]);
     const u32 up = __shfl_up(inc, 1, 64);
     if (lane > 0) carry = max(carry, up);
-    L.r0 = carry - 1u;
-    // count
-    u32 r0 = L.r0, tot = 0;
+    const u32 r0 = carry - 1u; // start of the run that enters byte 0
+    // a chunk ends at byte j when the next byte differs or lies beyond the block (or at 255 bytes)
+    const bool d15 = (EDGE && pos + 16u >= e) || nxt != (L.w[3] >> 24);
+    const u32 brk = (((heads | ~valid) >> 1) & 0x7fffu) | (d15 ? 0x8000u : 0u);
+    u32 k = pos >= r0 ? (pos - r0 + 254u) % 255u : 0u;
+    L.kprev = k;
+    u32 lit = 0, cnt = 0;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
-        const u32 i = pos + j;
-        if ((heads >> j) & 1u) r0 = i;
-        if (i >= s && i < e) {
-            u32 k = i - r0;
-            if (k >= 255u) k %= 255u;
-            const u32 c = (L.w[j >> 2] >> (8 * (j & 3))) & 255u;
-            const u32 cn = j < 15 ? ((L.w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 255u) : nxt;
-            const bool chunk_end = (k == 254u) || (i + 1 == e) || (cn != c);
-            tot += (k < 4u ? 1u : 0u) + ((chunk_end && k >= 3u) ? 1u : 0u);
-        }
+        k = (k == 254u) ? 0u : k + 1u;
+        k = ((heads >> j) & 1u) ? 0u : k;
+        const bool ends = ((brk >> j) & 1u) || k == 254u;
+        lit |= (k < 4u) ? 1u << j : 0u;
+        cnt |= (ends && k >= 3u) ? 1u << j : 0u;
     }
-    return tot;
+    L.lit = lit & valid;
+    L.cnt = cnt & valid;
+    return (u32)__popc(L.lit) + (u32)__popc(L.cnt);
 }
 
 #define K1_EMIT_STAGE (K1_TILE + K1_TILE / 4 + 64) // a run of 4 emits 5 bytes: at most 1.25 per input byte
@@ -690,17 +703,10 @@ __device__ __forceinline__ u32 emit_base(const u8 *__restrict__ in, const u32 *_
     return enc0 + (agg_c[gt] - pre) + (head ? enc_rem(k) : min(k, 4u));
 }
 
-__global__ __launch_bounds__(256) void k1_emit(const u8 *__restrict__ in,
-                                               const u32 *__restrict__ agg_head,
-                                               const u32 *__restrict__ agg_c,
-                                               const u32 *__restrict__ starts,
-                                               const u32 *__restrict__ binfo, u8 *__restrict__ T,
-                                               u32 *__restrict__ present, u32 *__restrict__ nOut, u32 S) {
-    const u32 b = blockIdx.y;
-    const u32 s = starts[b], e = starts[b + 1];
-    const u32 gt = s / K1_TILE + blockIdx.x;
-    if (gt * K1_TILE >= e) return;
-    const u32 ebase = emit_base(in, agg_head, agg_c, binfo, b, s, gt);
+template <bool EDGE>
+__device__ __forceinline__ void emit_tile(const u8 *__restrict__ in, const u32 *__restrict__ agg_head,
+                                          u32 s, u32 e, u32 gt, u32 ebase, u32 b, u8 *__restrict__ T,
+                                          u32 *__restrict__ present, u32 *__restrict__ nOut, u32 S) {
     __shared__ u32 sm[8];
     __shared__ u32 red[8];
     __shared__ u32 pres[8 * 8]; // the bitmap's 8 words, each 8 times (lane mod 8): atomics of one wave on one word are served one by one
@@ -708,31 +714,24 @@ __global__ __launch_bounds__(256) void k1_emit(const u8 *__restrict__ in,
     if (threadIdx.x < 64) pres[threadIdx.x] = 0;
     u32 *const mypres = pres + (threadIdx.x & 7u);
     EmitLane L;
-    const u32 tot = emit_lane(in, agg_head, s, e, gt, sm, L);
+    const u32 tot = emit_lane<EDGE>(in, agg_head, s, e, gt, sm, L);
     u32 total;
     u32 o = block_excl_scan_add<256>(tot, red, &total); // has a barrier after pres is cleared
-    // the thread's bytes into the staging tile (a value enters the bitmap once per run)
-    const u32 pos = gt * K1_TILE + threadIdx.x * 16u;
-    u32 r0 = L.r0;
+    // the thread's bytes into the staging tile (a value enters the bitmap once per run: at its head)
+    u32 k = L.kprev;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
-        const u32 i = pos + j;
-        if ((L.heads >> j) & 1u) r0 = i;
-        if (i >= s && i < e) {
-            u32 k = i - r0;
-            if (k >= 255u) k %= 255u;
-            const u32 c = (L.w[j >> 2] >> (8 * (j & 3))) & 255u;
-            const u32 cn = j < 15 ? ((L.w[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 255u) : L.nxt;
-            const bool chunk_end = (k == 254u) || (i + 1 == e) || (cn != c);
-            if (k < 4u) {
-                stage[o++] = (u8)c;
-                if (k == 0u) atomicOr(&mypres[(c >> 5) * 8u], 1u << (c & 31));
-            }
-            if (chunk_end && k >= 3u) {
-                const u32 cb = k - 3u;
-                stage[o++] = (u8)cb;
-                atomicOr(&mypres[(cb >> 5) * 8u], 1u << (cb & 31));
-            }
+        k = (k == 254u) ? 0u : k + 1u;
+        k = ((L.heads >> j) & 1u) ? 0u : k;
+        const u32 c = (L.w[j >> 2] >> (8 * (j & 3))) & 255u;
+        if ((L.lit >> j) & 1u) {
+            stage[o++] = (u8)c;
+            if ((L.heads >> j) & 1u) atomicOr(&mypres[(c >> 5) * 8u], 1u << (c & 31));
+        }
+        if ((L.cnt >> j) & 1u) {
+            const u32 cb = k - 3u;
+            stage[o++] = (u8)cb;
+            atomicOr(&mypres[(cb >> 5) * 8u], 1u << (cb & 31));
         }
     }
     __syncthreads();
@@ -754,13 +753,29 @@ __global__ __launch_bounds__(256) void k1_emit(const u8 *__restrict__ in,
         const u32 done = headn + nwords * 4u;
         if (threadIdx.x < total - done) out[done + threadIdx.x] = stage[done + threadIdx.x];
     }
-    if (threadIdx.x == 0 && gt == (e - 1) / K1_TILE) nOut[b] = ebase + total; // the block's last tile
+    if (EDGE && threadIdx.x == 0 && gt == (e - 1) / K1_TILE) nOut[b] = ebase + total; // the block's last tile
     if (threadIdx.x < 8) {
         u32 v = 0;
 #pragma unroll
         for (int r = 0; r < 8; r++) v |= pres[threadIdx.x * 8 + r];
         if (v) atomicOr(&present[b * 8 + threadIdx.x], v);
     }
+}
+
+__global__ __launch_bounds__(256) void k1_emit(const u8 *__restrict__ in,
+                                               const u32 *__restrict__ agg_head,
+                                               const u32 *__restrict__ agg_c,
+                                               const u32 *__restrict__ starts,
+                                               const u32 *__restrict__ binfo, u8 *__restrict__ T,
+                                               u32 *__restrict__ present, u32 *__restrict__ nOut, u32 S) {
+    const u32 b = blockIdx.y;
+    const u32 s = starts[b], e = starts[b + 1];
+    const u32 gt = s / K1_TILE + blockIdx.x;
+    if (gt * K1_TILE >= e) return;
+    const u32 ebase = emit_base(in, agg_head, agg_c, binfo, b, s, gt);
+    // inner tile: begins after s and ends before the block's last byte
+    if (gt * K1_TILE > s && (gt + 1u) * K1_TILE < e) emit_tile<false>(in, agg_head, s, e, gt, ebase, b, T, present, nOut, S);
+    else emit_tile<true>(in, agg_head, s, e, gt, ebase, b, T, present, nOut, S);
 }
 
 // ---------------------------------------------------------------- CRC
