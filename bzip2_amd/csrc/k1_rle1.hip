@@ -23,26 +23,42 @@
 
 __device__ __forceinline__ u32 enc_rem(u32 r) { return r < 4 ? r : 5u; }
 
-// phase 1: last head position + 1 per tile
+// phase 1: last head position + 1 per tile.  16 consecutive bytes per thread (one 16-byte load when
+// the input is aligned and the 16 lie below n), the byte before them from the neighbouring lane.
 __global__ __launch_bounds__(256) void k1_heads_p1(const u8 *__restrict__ in, u32 n,
                                                    u32 *__restrict__ agg, u32 tile0) {
     const u32 tile = tile0 + blockIdx.x;
-    const u32 base = tile * K1_TILE;
+    const u32 pos = tile * K1_TILE + threadIdx.x * 16u;
     __shared__ u32 sm[8];
-    u32 last = 0;
-    // unconditional (clamped) loads first: 32 byte loads in flight per thread
-    u8 c0[16], c1[16];
+    u32 w[4];
+    if (pos + 16u <= n && (((uintptr_t)(in + pos)) & 15u) == 0) {
+        const uint4 v = *(const uint4 *)(in + pos);
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    } else {
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const u32 i = base + k * 256 + threadIdx.x;
-        const u32 ic = i < n ? i : n - 1;
-        c0[k] = in[ic];
-        c1[k] = in[ic ? ic - 1 : 0];
+        for (int q = 0; q < 4; q++) {
+            u32 x = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const u32 i = pos + q * 4 + j;
+                if (i < n) x |= (u32)in[i] << (8 * j);
+            }
+            w[q] = x;
+        }
     }
+    u32 prv = __shfl_up(w[3] >> 24, 1, 64);
+    if (lane_id() == 0 && pos > 0 && pos < n) prv = in[pos - 1];
+    // bytes that differ from the byte before them: x = the 16 bytes xor the 16 shifted up by one
+    u32 last = 0;
+    u32 pb = prv;
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const u32 i = base + k * 256 + threadIdx.x;
-        if (i < n && (i == 0 || c0[k] != c1[k])) last = i + 1;
+    for (int q = 0; q < 4; q++) {
+        const u32 sh = (w[q] << 8) | pb;
+        pb = w[q] >> 24;
+        u32 x = w[q] ^ sh; // byte j != 0: a head at pos + 4q + j
+        if (pos + 4u * q + 4u > n) x &= (pos + 4u * q >= n) ? 0u : (0xffffffffu >> (8u * (pos + 4u * q + 4u - n)));
+        if (pos == 0 && q == 0) x |= 1u; // position 0 is a head
+        if (x) last = pos + 4u * q + (31u - (u32)__clz(x)) / 8u + 1u;
     }
     u32 t = block_reduce_max<256>(last, sm);
     if (threadIdx.x == 0) agg[tile] = t;
