@@ -193,8 +193,12 @@ static void ensure_window(bz2hip_ctx *c, size_t wlen, int level) {
     }
 }
 
-static void ensure_staging(bz2hip_ctx *c, size_t in_bytes, size_t out_bytes) {
+// (returns whether the input staging buffer was replaced: what had been uploaded into it is gone,
+// even when the new buffer has the old one's address)
+static bool ensure_staging(bz2hip_ctx *c, size_t in_bytes, size_t out_bytes) {
+    bool in_replaced = false;
     if (c->h_in_cap < in_bytes) {
+        in_replaced = true;
         c->h_in_cap = 0;
         if (c->h_in) (void)hipFree(c->h_in);
         c->h_in = nullptr;
@@ -208,6 +212,7 @@ static void ensure_staging(bz2hip_ctx *c, size_t in_bytes, size_t out_bytes) {
         HIPCHK(hipMalloc((void **)&c->h_out, out_bytes + 64));
         c->h_out_cap = out_bytes;
     }
+    return in_replaced;
 }
 
 // ------------------------------------------------------------------ error plumbing
@@ -870,6 +875,14 @@ struct ShardJob {
     int rc = BZ2HIP_OK;
 };
 
+// Transfers between the callers' pageable buffers and the devices, and the workspace (re)allocations
+// next to them, are taken one worker at a time.  Seen on this stack (ROCm 7.2): with three workers
+// uploading at once, one worker's hipMemcpyAsync of 7.95 MB from pageable memory delivered its last
+// 613 280 bytes and left the 7 MiB before them untouched (the stream decoded to zeros there); twice in
+// ~40 runs of the test suite, only in the first process on a fresh machine.  The copies are short
+// next to the compression they feed; the kernels of the workers still overlap.
+static std::mutex g_pageable_mu;
+
 struct ChainHop {
     std::mutex m;
     std::condition_variable cv;
@@ -903,14 +916,18 @@ static void shard_phase1(ShardJob &J, size_t r, size_t nw, const u8 *in, size_t 
             const size_t end = std::min(n, J.hi + look);
             const size_t avail = end - J.lo;
             if (avail > WMAX) return fail(x, BZ2HIP_E_PARAM, "internal: shard larger than one window");
-            const u8 *old = x->h_in;
-            ensure_staging(x, avail, bz2hip_compress_bound(avail));
-            if (x->h_in != old) uploaded = 0;
-            if (avail > uploaded)
-                HIPCHK(hipMemcpyAsync(x->h_in + uploaded, in + J.lo + uploaded, avail - uploaded,
-                                      hipMemcpyHostToDevice, x->stream));
-            uploaded = avail;
-            int rc = bz2hip_shard_scan(x, x->h_in, avail, level);
+            int rc;
+            {
+                std::lock_guard<std::mutex> g(g_pageable_mu);
+                if (ensure_staging(x, avail, bz2hip_compress_bound(avail))) uploaded = 0;
+                if (avail > uploaded) {
+                    HIPCHK(hipMemcpyAsync(x->h_in + uploaded, in + J.lo + uploaded, avail - uploaded,
+                                          hipMemcpyHostToDevice, x->stream));
+                    HIPCHK(hipStreamSynchronize(x->stream));
+                }
+                uploaded = avail;
+                rc = bz2hip_shard_scan(x, x->h_in, avail, level); // (allocates; its kernels are only queued here)
+            }
             if (rc != BZ2HIP_OK) return rc;
             if (first < 0) first = hop.get(r);
             if (first == -2) return fail(x, BZ2HIP_E_STATE, "the shard before this one failed");
@@ -953,6 +970,7 @@ static void shard_phase2(ShardJob &J, u8 *out) {
     J.n_edges = 0;
     if (!J.nbits) return;
     J.rc = guarded(x, [&]() -> int {
+        std::lock_guard<std::mutex> g(g_pageable_mu);
         const u64 sh = J.off & 31;
         const size_t W = (size_t)((sh + J.nbits + 31) / 32);
         if (x->d_shift_cap < W * 4) {
