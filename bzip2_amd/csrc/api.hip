@@ -314,6 +314,7 @@ extern "C" int bz2hip_create(bz2hip_ctx **out, const bz2hip_opts *opts) {
     c->radix_dig = env_int("BZ2HIP_RADIX_DIG", 1) != 0;
     c->mtf_inv = env_int("BZ2HIP_MTF_INV", 1) != 0;
     c->split_hints = env_int("BZ2HIP_SPLIT_HINTS", 1);
+    c->r0_rank16 = env_int("BZ2HIP_R0RANK16", 1) != 0;
     c->tie_poison = env_int("BZ2HIP_TIE_POISON", 0) != 0; // tests: cached origin pointers are stored wrong
     c->stream_chunk = (size_t)std::max(1, env_int("BZ2HIP_STREAM_CHUNK_MIB", (int)(STREAM_CHUNK >> 20))) << 20;
     c->stream_sync = env_int("BZ2HIP_STREAM_SYNC", 0) != 0;

@@ -168,6 +168,7 @@ struct bz2hip_ctx {
     u32 r0bits = 40;         // BZ2HIP_R0BITS
     u32 r0_sweeps = 2;       // BZ2HIP_RSWEEPS
     bool mtf_inv = true;
+    bool r0_rank16 = true;   // round-0 re-rank with 16 consecutive slots per thread (experiments: BZ2HIP_R0RANK16=0)
     int split_hints = 1;     // k1_hints before the block chain: 0 never, 1 when more than 8 blocks lie ahead, 2 always (tests)     // BZ2HIP_MTF_INV: MTF replay as inversion counts (k3_mtf_replay_inv) instead of the loop over run heads
     bool radix_dig = true;   // BZ2HIP_RADIX_DIG: a scatter pass leaves the next pass's digits as a byte array
     bool r0_rule = true;     // BZ2HIP_R0RULE: the run rule already in the re-rank of round 0

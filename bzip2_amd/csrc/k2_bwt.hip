@@ -1075,6 +1075,301 @@ __global__ __launch_bounds__(RT_THREADS) void k2_lrerank_p3(
                     nsw > 1 ? sweep * win : 0u, nsw > 1 ? (sweep + 1) * win : ~0u, sweep == 0);
 }
 
+// ------------------------------------------------------------------ round-0 re-rank, 16 consecutive elements per thread
+// The same classification and outputs as k2_lrerank_p1 / p3<MODE_ROUND0>, laid out the other way:
+// a thread owns 16 consecutive slots of the tile (read from the swizzled LDS copy) and walks them
+// with "slot of my group's head" / "slot of the next head" in registers; what enters a thread is a
+// max-scan (last head before) and a suffix min-scan (first head behind) over the threads.  The
+// row-per-wave-step layout pays ballots and 64-bit mask arithmetic per row of 64 (75 vector
+// instructions per row in tile_classify alone); here the cross-lane work is paid per 1024 slots.
+struct R0Cls {
+    u64 e[16];
+    int hd[16];  // tile-local slot of the group head (negative: the group entered from an earlier tile)
+    int nxt[16]; // tile-local slot of the next head behind the element (cnt, or CROSS)
+    u32 heads;   // bit k: element k is a head
+    u32 valid;   // bit k: element k exists
+    u32 cls;     // 2 bits per element: CLS_*
+};
+
+template <bool CLASSES>
+__device__ __forceinline__ void r0_classify(const u64 *buf, int cnt, u64 prevE, bool has_prev, int carryNew,
+                                            bool end_head, int *sm /* 16 ints */, R0Cls &R, u64 &pe,
+                                            int &nheads, int &lastHeadTile) {
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const int q0 = tid * 16;
+#pragma unroll
+    for (int k = 0; k < 16; k++) R.e[k] = buf[SZ(q0 + k)];
+    pe = tid ? buf[SZ(tid ? q0 - 1 : 0)] : prevE; // the element before the thread's first
+    u32 heads = 0, valid = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const bool v = q0 + k < cnt;
+        bool h;
+        if (k == 0) h = (tid == 0 && !has_prev) || (R.e[0] >> KEY_SHIFT) != (pe >> KEY_SHIFT);
+        else h = (R.e[k] >> KEY_SHIFT) != (R.e[k - 1] >> KEY_SHIFT);
+        heads |= (h && v) ? 1u << k : 0u;
+        valid |= v ? 1u << k : 0u;
+    }
+    R.heads = heads;
+    R.valid = valid;
+    const u32 lastp1 = heads ? (u32)q0 + (31u - (u32)__clz(heads)) + 1u : 0u;
+    const u32 firstv = heads ? (u32)q0 + (u32)__ffs(heads) - 1u : 0xffffffffu;
+    const u32 inc = wave_incl_scan_max(lastp1);
+    u32 suf = firstv; // inclusive suffix minimum over the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 o = __shfl_down(suf, d, 64);
+        if (lane + d < 64) suf = min(suf, o);
+    }
+    const u32 hc = wave_reduce_add((u32)__popc(heads));
+    __syncthreads();
+    if (lane == 63) sm[w] = (int)inc;
+    if (lane == 0) {
+        sm[4 + w] = (int)suf;
+        sm[8 + w] = (int)hc;
+    }
+    __syncthreads();
+    u32 before = 0;
+    for (int q = 0; q < w; q++) before = max(before, (u32)sm[q]);
+    const u32 up = __shfl_up(inc, 1, 64);
+    if (lane > 0) before = max(before, up);
+    u32 after = 0xffffffffu;
+    for (int q = 3; q > w; q--) after = min(after, (u32)sm[4 + q]);
+    const u32 dn = __shfl_down(suf, 1, 64);
+    if (lane < 63) after = min(after, dn);
+    nheads = sm[8] + sm[9] + sm[10] + sm[11];
+    lastHeadTile = (int)max(max((u32)sm[0], (u32)sm[1]), max((u32)sm[2], (u32)sm[3])) - 1;
+    int cur = before ? (int)before - 1 : carryNew;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        if ((heads >> k) & 1u) cur = q0 + k;
+        R.hd[k] = cur;
+    }
+    if (CLASSES) {
+        int nx = after != 0xffffffffu ? (int)after : (end_head ? cnt : CROSS);
+        u32 cls = 0;
+#pragma unroll
+        for (int k = 15; k >= 0; k--) {
+            R.nxt[k] = nx;
+            int c = CLS_NONE;
+            if ((valid >> k) & 1u) {
+                if (R.hd[k] < 0 || nx == CROSS) c = CLS_LKEEP;
+                else {
+                    const int size = nx - R.hd[k];
+                    c = (size == 1) ? CLS_SINGLE : (size <= GS ? CLS_SMALL : CLS_LKEEP);
+                }
+            }
+            cls |= (u32)c << (2 * k);
+            if ((heads >> k) & 1u) nx = q0 + k;
+        }
+        R.cls = cls;
+    }
+}
+
+// round0_run_rule on this layout: groups inside the tile that lie in one recorded region at one
+// distance are finished here (class SINGLE, rank = head + slot or its reverse)
+__device__ __forceinline__ void r0_rule(const u64 *buf, R0Cls &R, u64 pe, u32 (&rk)[16], u8 *gflag /* [RTILE] */,
+                                        const u32 *s_runs, u32 d0) {
+    const u32 nr = s_runs[0];
+    if (nr == 0) return; // (uniform over the workgroup: s_runs is shared)
+    const int q0 = threadIdx.x * 16;
+    for (int q = threadIdx.x; q < RTILE / 4; q += RT_THREADS) ((u32 *)gflag)[q] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int c = (int)((R.cls >> (2 * k)) & 3u);
+        const int gsz = (R.hd[k] >= 0 && R.nxt[k] != CROSS) ? R.nxt[k] - R.hd[k] : 0;
+        if ((c == CLS_SMALL || c == CLS_LKEEP) && gsz > 1) {
+            const int slot = q0 + k - R.hd[k];
+            if (slot >= 1) {
+                const u64 e = R.e[k], ep = k ? R.e[k ? k - 1 : 0] : pe;
+                const u32 i1 = (u32)(e & E_IMASK), i0 = (u32)(ep & E_IMASK);
+                const u32 d = i1 - i0;
+                u32 f = GF_R0_BAD;
+                if (i1 > i0 && d > d0) {
+                    u32 ok = 0;
+                    for (u32 r = 0; r < nr; r++) {
+                        const u32 *Rg = s_runs + 4 + 4 * r;
+                        if (Rg[0] == d && i0 >= Rg[1] && i1 <= Rg[2]) ok = Rg[3];
+                    }
+                    if (ok) f = GF_R0_RUN | ok;
+                }
+                if (slot >= 2) {
+                    const u64 epp = k >= 2 ? R.e[k >= 2 ? k - 2 : 0] : (k == 1 ? pe : buf[SZ(q0 + k >= 2 ? q0 + k - 2 : 0)]);
+                    if (i0 - (u32)(epp & E_IMASK) != d) f |= GF_R0_BAD;
+                }
+                const int h = R.hd[k];
+                atomicOr((u32 *)gflag + (h >> 2), f << ((h & 3) * 8));
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int c = (int)((R.cls >> (2 * k)) & 3u);
+        const int gsz = (R.hd[k] >= 0 && R.nxt[k] != CROSS) ? R.nxt[k] - R.hd[k] : 0;
+        if ((c == CLS_SMALL || c == CLS_LKEEP) && gsz > 1) {
+            const int slot = q0 + k - R.hd[k];
+            const u32 gf = gflag[R.hd[k]];
+            const u32 dir = gf & (GF_R0_ASC | GF_R0_DESC);
+            if ((gf & GF_R0_RUN) && !(gf & GF_R0_BAD) && (dir == GF_R0_ASC || dir == GF_R0_DESC)) {
+                R.cls = (R.cls & ~(3u << (2 * k))) | ((u32)CLS_SINGLE << (2 * k));
+                rk[k] += (dir == GF_R0_ASC) ? (u32)slot : (u32)(gsz - 1 - slot);
+            }
+        }
+    }
+}
+
+// loads the tile into the swizzled LDS copy (16 loads in flight; the slot is padded to whole tiles)
+__device__ __forceinline__ void r0_tile_to_lds(const u64 *__restrict__ kp, u32 base, int cnt, u64 *buf) {
+    u64 tmp[RT_ITEMS];
+#pragma unroll
+    for (int k = 0; k < RT_ITEMS; k++) tmp[k] = __builtin_nontemporal_load(&kp[base + k * RT_THREADS + threadIdx.x]);
+#pragma unroll
+    for (int k = 0; k < RT_ITEMS; k++) {
+        const int q = k * RT_THREADS + threadIdx.x;
+        buf[SZ(q)] = (q < cnt) ? tmp[k] : ~0ull;
+    }
+}
+
+// phase 1: per tile {last old head + 1, last new head + 1, LKEEP count, heads}
+__global__ __launch_bounds__(RT_THREADS) void k2_r0rank_p1(const u64 *__restrict__ key,
+                                                           const u32 *__restrict__ cntArr,
+                                                           const u32 *__restrict__ state, u32 want,
+                                                           u32 *__restrict__ tileagg, u32 S, u32 TPB, u32 gtiles, u32 gnb,
+                                                           const u32 *__restrict__ huse, const u32 *__restrict__ runs) {
+    XCD_MAP(gtiles, gnb)
+    const u32 b = bz_b;
+    if (state[b] != want) return;
+    const u32 m = cntArr[b];
+    const u32 base = bz_t * RTILE;
+    if (base >= m) return;
+    __shared__ u64 buf[RTILE];
+    __shared__ int sm[16];
+    __shared__ __attribute__((aligned(16))) u8 gflag[RTILE];
+    __shared__ u32 s_runs[RUNS_STRIDE];
+    __shared__ u32 red[8];
+    if (threadIdx.x < RUNS_STRIDE) s_runs[threadIdx.x] = runs ? runs[(size_t)b * RUNS_STRIDE + threadIdx.x] : 0u;
+    const u64 *kp = key + (size_t)b * S;
+    const int cnt = (int)min((u32)RTILE, m - base);
+    r0_tile_to_lds(kp, base, cnt, buf);
+    const bool has_prev = base > 0;
+    const u64 prevE = has_prev ? kp[base - 1] : 0;
+    bool end_head = true;
+    if (base + cnt < m) end_head = (kp[base + cnt] >> KEY_SHIFT) != (kp[base + cnt - 1] >> KEY_SHIFT);
+    __syncthreads();
+    R0Cls R;
+    u64 pe;
+    int nheads, lastHeadTile;
+    r0_classify<true>(buf, cnt, prevE, has_prev, NOHEAD, end_head, sm, R, pe, nheads, lastHeadTile);
+    u32 rk[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) rk[k] = 0;
+    r0_rule(buf, R, pe, rk, gflag, s_runs, huse[b]);
+    u32 keep = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) keep += ((R.cls >> (2 * k)) & 3u) == (u32)CLS_LKEEP;
+    const u32 tK = block_reduce_add<RT_THREADS>(keep, red);
+    if (threadIdx.x == 0) {
+        u32 *o = tileagg + ((size_t)b * TPB + bz_t) * 4;
+        o[0] = base == 0 ? 1u : 0u; // (round 0 has no old groups: only the block's first element counts as an old head)
+        o[1] = lastHeadTile >= 0 ? base + (u32)lastHeadTile + 1u : 0u;
+        o[2] = tK;
+        o[3] = (u32)nheads;
+    }
+}
+
+// phase 3: ranks (one position window per sweep), survivors to the S- and the L-list in slot order
+__global__ __launch_bounds__(RT_THREADS) void k2_r0rank_p3(
+    const u64 *__restrict__ key, u64 *__restrict__ lOutAll, u64 *slA, u64 *slB,
+    const u32 *__restrict__ par, const u32 *__restrict__ cntArr,
+    const u32 *__restrict__ state, u32 want, const u32 *__restrict__ tileagg,
+    u32 *__restrict__ rank, const u32 *__restrict__ nArr, u32 *__restrict__ mSn, u32 *__restrict__ gcount,
+    u32 S, u32 TPB, u32 gtiles, u32 gnb, u32 nsw, const u32 *__restrict__ huse, const u32 *__restrict__ runs) {
+    XCD_MAP(gtiles * nsw, gnb)
+    const u32 b = bz_b;
+    if (state[b] != want) return;
+    const u32 m = cntArr[b];
+    const u32 sweep = bz_t / gtiles;
+    bz_t -= sweep * gtiles;
+    const u32 base = bz_t * RTILE;
+    if (base >= m) return;
+    __shared__ u64 buf[RTILE];
+    __shared__ int sm[16];
+    __shared__ __attribute__((aligned(16))) u8 gflag[RTILE];
+    __shared__ u32 s_runs[RUNS_STRIDE];
+    __shared__ u32 red[8];
+    __shared__ u32 s_sbase;
+    if (threadIdx.x < RUNS_STRIDE) s_runs[threadIdx.x] = runs ? runs[(size_t)b * RUNS_STRIDE + threadIdx.x] : 0u;
+    const u64 *kp = key + (size_t)b * S;
+    const int cnt = (int)min((u32)RTILE, m - base);
+    r0_tile_to_lds(kp, base, cnt, buf);
+    const bool has_prev = base > 0;
+    const u64 prevE = has_prev ? kp[base - 1] : 0;
+    bool end_head = true;
+    if (base + cnt < m) end_head = (kp[base + cnt] >> KEY_SHIFT) != (kp[base + cnt - 1] >> KEY_SHIFT);
+    const u32 *ag = tileagg + ((size_t)b * TPB + bz_t) * 4;
+    const int carryNew = ag[1] ? (int)ag[1] - 1 - (int)base : NOHEAD;
+    const u32 lBase = ag[2];
+    __syncthreads();
+    const bool main_sweep = sweep == 0;
+    const bool rule = s_runs[0] != 0;
+    R0Cls R;
+    u64 pe;
+    int nheads, lastHeadTile;
+    // a later sweep needs the ranks only; classes (and the rule, which moves ranks) where regions exist
+    if (main_sweep || rule) r0_classify<true>(buf, cnt, prevE, has_prev, carryNew, end_head, sm, R, pe, nheads, lastHeadTile);
+    else r0_classify<false>(buf, cnt, prevE, has_prev, carryNew, end_head, sm, R, pe, nheads, lastHeadTile);
+    u32 rk[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) rk[k] = base + (u32)R.hd[k]; // (a group from an earlier tile: its head's position)
+    if (rule) r0_rule(buf, R, pe, rk, gflag, s_runs, huse[b]);
+    const u32 nblk = nArr[b], win = (nblk + nsw - 1) / nsw;
+    const u32 rlo = nsw > 1 ? sweep * win : 0u, rhi = nsw > 1 ? (sweep + 1) * win : ~0u;
+    u32 *rb = rank + (size_t)b * S;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const u32 i = (u32)(R.e[k] & E_IMASK);
+        if (((R.valid >> k) & 1u) && i >= rlo && i < rhi) rb[i] = rk[k];
+    }
+    if (!main_sweep) return;
+    // survivors: counts, offsets, then through LDS (the tile copy is no longer needed) in slot order
+    const int q0 = threadIdx.x * 16;
+    u32 cs = 0, cl = 0, ch = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const u32 c = (R.cls >> (2 * k)) & 3u;
+        cs += c == (u32)CLS_SMALL;
+        cl += c == (u32)CLS_LKEEP;
+        ch += (c == (u32)CLS_SMALL || c == (u32)CLS_LKEEP) && R.hd[k] == q0 + k;
+    }
+    u32 totS, totL;
+    u32 so = block_excl_scan_add<RT_THREADS>(cs, red, &totS);
+    __syncthreads();
+    u32 lo = block_excl_scan_add<RT_THREADS>(cl, red, &totL);
+    __syncthreads();
+    const u32 totH = block_reduce_add<RT_THREADS>(ch, red);
+    if (threadIdx.x == 0) {
+        s_sbase = totS ? atomicAdd(mSn + b, totS) : 0u;
+        if (totH) atomicAdd(gcount + b, totH);
+    }
+    __syncthreads(); // every thread has its elements in registers: buf becomes the staging area
+    lo += totS;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const u32 c = (R.cls >> (2 * k)) & 3u;
+        const u64 v = ((u64)rk[k] << 40) | (R.e[k] & E_IMASK);
+        if (c == (u32)CLS_SMALL) buf[so++] = v;
+        if (c == (u32)CLS_LKEEP) buf[lo++] = v;
+    }
+    __syncthreads();
+    u64 *sOut = (par[b] ? slA : slB) + (size_t)b * S + s_sbase;
+    u64 *lOut = lOutAll + (size_t)b * S + lBase;
+    // list traffic is streaming: keep it from evicting the rank lines being scattered into
+    for (u32 q = threadIdx.x; q < totS; q += RT_THREADS) __builtin_nontemporal_store(buf[q], &sOut[q]);
+    for (u32 q = threadIdx.x; q < totL; q += RT_THREADS) __builtin_nontemporal_store(buf[totS + q], &lOut[q]);
+}
+
 // ------------------------------------------------------------------ S-path: sort in LDS
 // Bitonic sort of buf[0..N) (swizzled indexing, N a power of two >= 64).  The network's
 // sub-stages are grouped by the bit they exchange on: [0,4), [4,8), [8,12).  For each group a
@@ -2120,17 +2415,27 @@ static void lrerank(bz2hip_ctx *c, int nb, u32 maxcnt, const u32 *cntArr, u32 wa
     dim3 grid(tiles, nb);
     ProfScope ps(c, P_BWT_RERANK);
     const u32 *r0runs = (MODE == MODE_ROUND0 && c->r0_rule) ? B.runs : nullptr;
-    k2_lrerank_p1<MODE><<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(sorted, cntArr, B.state, want,
-                                                                           B.tileagg, B.S, B.TPB, tiles, nbarg(nb, 4),
-                                                                           B.huse, r0runs);
+    const bool serial16 = MODE == MODE_ROUND0 && c->r0_rank16; // round 0: 16 consecutive slots per thread
+    if (serial16)
+        k2_r0rank_p1<<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(sorted, cntArr, B.state, want, B.tileagg, B.S,
+                                                                        B.TPB, tiles, nbarg(nb, 4), B.huse, r0runs);
+    else
+        k2_lrerank_p1<MODE><<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(sorted, cntArr, B.state, want,
+                                                                               B.tileagg, B.S, B.TPB, tiles, nbarg(nb, 4),
+                                                                               B.huse, r0runs);
     KCHECK();
     k2_lrerank_p2<<<nb, 256, 0, c->stream>>>(cntArr, B.state, want, B.tileagg, B.mLn, B.leftg,
                                              MODE == MODE_FINAL ? 1 : 0, B.TPB);
     KCHECK();
     const u32 nsw = (MODE == MODE_ROUND0) ? c->r0_sweeps : 1u;
-    k2_lrerank_p3<MODE><<<xcd_grid(tiles * nsw, nb), RT_THREADS, 0, c->stream>>>(
-        sorted, lout, B.slA, B.slB, B.par, cntArr, B.state, want, B.tileagg, B.rank, B.T, B.bwt, B.n,
-        B.mSn, B.nheads, B.S, B.TPB, tiles, nbarg(nb, 4), nsw, B.huse, r0runs);
+    if (serial16)
+        k2_r0rank_p3<<<xcd_grid(tiles * nsw, nb), RT_THREADS, 0, c->stream>>>(
+            sorted, lout, B.slA, B.slB, B.par, cntArr, B.state, want, B.tileagg, B.rank, B.n, B.mSn, B.nheads, B.S,
+            B.TPB, tiles, nbarg(nb, 4), nsw, B.huse, r0runs);
+    else
+        k2_lrerank_p3<MODE><<<xcd_grid(tiles * nsw, nb), RT_THREADS, 0, c->stream>>>(
+            sorted, lout, B.slA, B.slB, B.par, cntArr, B.state, want, B.tileagg, B.rank, B.T, B.bwt, B.n,
+            B.mSn, B.nheads, B.S, B.TPB, tiles, nbarg(nb, 4), nsw, B.huse, r0runs);
     KCHECK();
 }
 
