@@ -1085,33 +1085,43 @@ __global__ __launch_bounds__(RT_THREADS) void k2_lrerank_p3(
 struct R0Cls {
     u64 e[16];
     int hd[16];  // tile-local slot of the group head (negative: the group entered from an earlier tile)
+    int ohd[16]; // (doubling rounds only) tile-local slot of the head of the element's OLD group
     int nxt[16]; // tile-local slot of the next head behind the element (cnt, or CROSS)
     u32 heads;   // bit k: element k is a head
     u32 valid;   // bit k: element k exists
     u32 cls;     // 2 bits per element: CLS_*
 };
 
-template <bool CLASSES>
+// MODE_ROUND0: one kind of head (the key changes).  MODE_NORMAL (doubling rounds): old heads (grp changes) as
+// well, for the rank base of an element: its old group's rank + the distance of its new head from the old one.
+template <bool CLASSES, int MODE = MODE_ROUND0>
 __device__ __forceinline__ void r0_classify(const u64 *buf, int cnt, u64 prevE, bool has_prev, int carryNew,
                                             bool end_head, int *sm /* 16 ints */, R0Cls &R, u64 &pe,
-                                            int &nheads, int &lastHeadTile) {
+                                            int &nheads, int &lastHeadTile, int carryOld = NOHEAD,
+                                            int *lastOldTile = nullptr) {
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     const int q0 = tid * 16;
 #pragma unroll
     for (int k = 0; k < 16; k++) R.e[k] = buf[SZ(q0 + k)];
     pe = tid ? buf[SZ(tid ? q0 - 1 : 0)] : prevE; // the element before the thread's first
-    u32 heads = 0, valid = 0;
+    u32 heads = 0, valid = 0, oheads = 0;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         const bool v = q0 + k < cnt;
-        bool h;
-        if (k == 0) h = (tid == 0 && !has_prev) || (R.e[0] >> KEY_SHIFT) != (pe >> KEY_SHIFT);
-        else h = (R.e[k] >> KEY_SHIFT) != (R.e[k - 1] >> KEY_SHIFT);
+        const u64 ep = k ? R.e[k ? k - 1 : 0] : pe;
+        const bool first = k == 0 && tid == 0 && !has_prev;
+        const bool h = first || (R.e[k] >> KEY_SHIFT) != (ep >> KEY_SHIFT);
         heads |= (h && v) ? 1u << k : 0u;
         valid |= v ? 1u << k : 0u;
+        if (MODE == MODE_NORMAL) {
+            const bool oh = first || (R.e[k] >> 40) != (ep >> 40);
+            oheads |= (oh && v) ? 1u << k : 0u;
+        }
     }
     R.heads = heads;
     R.valid = valid;
+    u32 oinc = 0;
+    if (MODE == MODE_NORMAL) oinc = wave_incl_scan_max(oheads ? (u32)q0 + (31u - (u32)__clz(oheads)) + 1u : 0u);
     const u32 lastp1 = heads ? (u32)q0 + (31u - (u32)__clz(heads)) + 1u : 0u;
     const u32 firstv = heads ? (u32)q0 + (u32)__ffs(heads) - 1u : 0xffffffffu;
     const u32 inc = wave_incl_scan_max(lastp1);
@@ -1123,7 +1133,10 @@ __device__ __forceinline__ void r0_classify(const u64 *buf, int cnt, u64 prevE, 
     }
     const u32 hc = wave_reduce_add((u32)__popc(heads));
     __syncthreads();
-    if (lane == 63) sm[w] = (int)inc;
+    if (lane == 63) {
+        sm[w] = (int)inc;
+        if (MODE == MODE_NORMAL) sm[12 + w] = (int)oinc;
+    }
     if (lane == 0) {
         sm[4 + w] = (int)suf;
         sm[8 + w] = (int)hc;
@@ -1133,6 +1146,19 @@ __device__ __forceinline__ void r0_classify(const u64 *buf, int cnt, u64 prevE, 
     for (int q = 0; q < w; q++) before = max(before, (u32)sm[q]);
     const u32 up = __shfl_up(inc, 1, 64);
     if (lane > 0) before = max(before, up);
+    if (MODE == MODE_NORMAL) {
+        u32 obefore = 0;
+        for (int q = 0; q < w; q++) obefore = max(obefore, (u32)sm[12 + q]);
+        const u32 oup = __shfl_up(oinc, 1, 64);
+        if (lane > 0) obefore = max(obefore, oup);
+        int ocur = obefore ? (int)obefore - 1 : carryOld;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if ((oheads >> k) & 1u) ocur = q0 + k;
+            R.ohd[k] = ocur;
+        }
+        if (lastOldTile) *lastOldTile = (int)max(max((u32)sm[12], (u32)sm[13]), max((u32)sm[14], (u32)sm[15])) - 1;
+    }
     u32 after = 0xffffffffu;
     for (int q = 3; q > w; q--) after = min(after, (u32)sm[4 + q]);
     const u32 dn = __shfl_down(suf, 1, 64);
@@ -1368,6 +1394,128 @@ __global__ __launch_bounds__(RT_THREADS) void k2_r0rank_p3(
     // list traffic is streaming: keep it from evicting the rank lines being scattered into
     for (u32 q = threadIdx.x; q < totS; q += RT_THREADS) __builtin_nontemporal_store(buf[q], &sOut[q]);
     for (u32 q = threadIdx.x; q < totL; q += RT_THREADS) __builtin_nontemporal_store(buf[totS + q], &lOut[q]);
+}
+
+// The re-rank of a doubling round's L-list on the same layout (k2_lrerank_p1 / p3<MODE_NORMAL>)
+__global__ __launch_bounds__(RT_THREADS) void k2_lrank16_p1(const u64 *__restrict__ key,
+                                                            const u32 *__restrict__ cntArr,
+                                                            const u32 *__restrict__ state, u32 want,
+                                                            u32 *__restrict__ tileagg, u32 S, u32 TPB, u32 gtiles, u32 gnb) {
+    XCD_MAP(gtiles, gnb)
+    const u32 b = bz_b;
+    if (state[b] != want) return;
+    const u32 m = cntArr[b];
+    const u32 base = bz_t * RTILE;
+    if (base >= m) return;
+    __shared__ u64 buf[RTILE];
+    __shared__ int sm[16];
+    __shared__ u32 red[8];
+    const u64 *kp = key + (size_t)b * S;
+    const int cnt = (int)min((u32)RTILE, m - base);
+    r0_tile_to_lds(kp, base, cnt, buf);
+    const bool has_prev = base > 0;
+    const u64 prevE = has_prev ? kp[base - 1] : 0;
+    bool end_head = true;
+    if (base + cnt < m) end_head = (kp[base + cnt] >> KEY_SHIFT) != (kp[base + cnt - 1] >> KEY_SHIFT);
+    __syncthreads();
+    R0Cls R;
+    u64 pe;
+    int nheads, lastHeadTile, lastOldTile;
+    r0_classify<true, MODE_NORMAL>(buf, cnt, prevE, has_prev, NOHEAD, end_head, sm, R, pe, nheads, lastHeadTile, NOHEAD,
+                                   &lastOldTile);
+    u32 keep = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) keep += ((R.cls >> (2 * k)) & 3u) == (u32)CLS_LKEEP;
+    const u32 tK = block_reduce_add<RT_THREADS>(keep, red);
+    if (threadIdx.x == 0) {
+        u32 *o = tileagg + ((size_t)b * TPB + bz_t) * 4;
+        o[0] = lastOldTile >= 0 ? base + (u32)lastOldTile + 1u : 0u;
+        o[1] = lastHeadTile >= 0 ? base + (u32)lastHeadTile + 1u : 0u;
+        o[2] = tK;
+        o[3] = (u32)nheads;
+    }
+}
+
+// ranks of the elements whose group changed, survivors to the S- and the L-list in slot order: what
+// tile_emit<MODE_NORMAL> does, from a thread's 16 consecutive elements, through LDS
+__device__ __forceinline__ void ts_emit_normal(u64 *buf, const R0Cls &R, u32 *__restrict__ rank_b,
+                                               u64 *__restrict__ sOut_b, u32 *mSn_b, u64 *__restrict__ lOut_b,
+                                               u32 lBase, u32 *gcount_b, u32 *red /* 8 */, u32 *s_sbase) {
+    const int q0 = threadIdx.x * 16;
+    u32 rk[16];
+    u32 cs = 0, cl = 0, ch = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const u32 gb = (u32)(R.e[k] >> 40);
+        rk[k] = gb + (u32)(R.hd[k] - R.ohd[k]);
+        const u32 c = (R.cls >> (2 * k)) & 3u;
+        cs += c == (u32)CLS_SMALL;
+        cl += c == (u32)CLS_LKEEP;
+        ch += (c == (u32)CLS_SMALL || c == (u32)CLS_LKEEP) && R.hd[k] == q0 + k;
+        // the first sub-group of a split group keeps its rank: no write
+        if (c != (u32)CLS_NONE && rk[k] != gb) rank_b[(u32)(R.e[k] & E_IMASK)] = rk[k];
+    }
+    u32 totS, totL;
+    u32 so = block_excl_scan_add<RT_THREADS>(cs, red, &totS);
+    __syncthreads();
+    u32 lo = block_excl_scan_add<RT_THREADS>(cl, red, &totL);
+    __syncthreads();
+    const u32 totH = block_reduce_add<RT_THREADS>(ch, red);
+    if (threadIdx.x == 0) {
+        *s_sbase = totS ? atomicAdd(mSn_b, totS) : 0u;
+        if (totH) atomicAdd(gcount_b, totH);
+    }
+    __syncthreads(); // every thread has its elements in registers: buf becomes the staging area
+    lo += totS;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const u32 c = (R.cls >> (2 * k)) & 3u;
+        const u64 v = ((u64)rk[k] << 40) | (R.e[k] & E_IMASK);
+        if (c == (u32)CLS_SMALL) buf[so++] = v;
+        if (c == (u32)CLS_LKEEP) buf[lo++] = v;
+    }
+    __syncthreads();
+    u64 *sOut = sOut_b + *s_sbase;
+    for (u32 q = threadIdx.x; q < totS; q += RT_THREADS) __builtin_nontemporal_store(buf[q], &sOut[q]);
+    if (lOut_b)
+        for (u32 q = threadIdx.x; q < totL; q += RT_THREADS) __builtin_nontemporal_store(buf[totS + q], &lOut_b[lBase + q]);
+}
+
+__global__ __launch_bounds__(RT_THREADS) void k2_lrank16_p3(
+    const u64 *__restrict__ key, u64 *__restrict__ lOutAll, u64 *slA, u64 *slB,
+    const u32 *__restrict__ par, const u32 *__restrict__ cntArr,
+    const u32 *__restrict__ state, u32 want, const u32 *__restrict__ tileagg,
+    u32 *__restrict__ rank, u32 *__restrict__ mSn, u32 *__restrict__ gcount,
+    u32 S, u32 TPB, u32 gtiles, u32 gnb) {
+    XCD_MAP(gtiles, gnb)
+    const u32 b = bz_b;
+    if (state[b] != want) return;
+    const u32 m = cntArr[b];
+    const u32 base = bz_t * RTILE;
+    if (base >= m) return;
+    __shared__ u64 buf[RTILE];
+    __shared__ int sm[16];
+    __shared__ u32 red[8];
+    __shared__ u32 s_sbase;
+    const u64 *kp = key + (size_t)b * S;
+    const int cnt = (int)min((u32)RTILE, m - base);
+    r0_tile_to_lds(kp, base, cnt, buf);
+    const bool has_prev = base > 0;
+    const u64 prevE = has_prev ? kp[base - 1] : 0;
+    bool end_head = true;
+    if (base + cnt < m) end_head = (kp[base + cnt] >> KEY_SHIFT) != (kp[base + cnt - 1] >> KEY_SHIFT);
+    const u32 *ag = tileagg + ((size_t)b * TPB + bz_t) * 4;
+    const int carryOld = ag[0] ? (int)ag[0] - 1 - (int)base : NOHEAD;
+    const int carryNew = ag[1] ? (int)ag[1] - 1 - (int)base : NOHEAD;
+    const u32 lBase = ag[2];
+    __syncthreads();
+    R0Cls R;
+    u64 pe;
+    int nheads, lastHeadTile;
+    r0_classify<true, MODE_NORMAL>(buf, cnt, prevE, has_prev, carryNew, end_head, sm, R, pe, nheads, lastHeadTile, carryOld);
+    // S survivors go to the buffer the S-kernel of this round also appends to
+    ts_emit_normal(buf, R, rank + (size_t)b * S, (par[b] ? slA : slB) + (size_t)b * S, mSn + b,
+                   lOutAll + (size_t)b * S, lBase, gcount + b, red, &s_sbase);
 }
 
 // ------------------------------------------------------------------ S-path: sort in LDS
@@ -2416,7 +2564,11 @@ static void lrerank(bz2hip_ctx *c, int nb, u32 maxcnt, const u32 *cntArr, u32 wa
     ProfScope ps(c, P_BWT_RERANK);
     const u32 *r0runs = (MODE == MODE_ROUND0 && c->r0_rule) ? B.runs : nullptr;
     const bool serial16 = MODE == MODE_ROUND0 && c->r0_rank16; // round 0: 16 consecutive slots per thread
-    if (serial16)
+    const bool normal16 = MODE == MODE_NORMAL && c->r0_rank16;
+    if (normal16)
+        k2_lrank16_p1<<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(sorted, cntArr, B.state, want, B.tileagg, B.S,
+                                                                         B.TPB, tiles, nbarg(nb, 4));
+    else if (serial16)
         k2_r0rank_p1<<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(sorted, cntArr, B.state, want, B.tileagg, B.S,
                                                                         B.TPB, tiles, nbarg(nb, 4), B.huse, r0runs);
     else
@@ -2428,7 +2580,11 @@ static void lrerank(bz2hip_ctx *c, int nb, u32 maxcnt, const u32 *cntArr, u32 wa
                                              MODE == MODE_FINAL ? 1 : 0, B.TPB);
     KCHECK();
     const u32 nsw = (MODE == MODE_ROUND0) ? c->r0_sweeps : 1u;
-    if (serial16)
+    if (normal16)
+        k2_lrank16_p3<<<xcd_grid(tiles, nb), RT_THREADS, 0, c->stream>>>(sorted, lout, B.slA, B.slB, B.par, cntArr,
+                                                                         B.state, want, B.tileagg, B.rank, B.mSn,
+                                                                         B.nheads, B.S, B.TPB, tiles, nbarg(nb, 4));
+    else if (serial16)
         k2_r0rank_p3<<<xcd_grid(tiles * nsw, nb), RT_THREADS, 0, c->stream>>>(
             sorted, lout, B.slA, B.slB, B.par, cntArr, B.state, want, B.tileagg, B.rank, B.n, B.mSn, B.nheads, B.S,
             B.TPB, tiles, nbarg(nb, 4), nsw, B.huse, r0runs);
