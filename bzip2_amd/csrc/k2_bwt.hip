@@ -235,17 +235,25 @@ __device__ __forceinline__ u64 r0_key(const R0Tile &L, u32 local, u32 i, u32 d0,
         const u32 w = local >> 2, a = local & 3u;
         const u32 w0 = t32[w], w1 = t32[w + 1], w2 = t32[w + 2];
         const u32 lo = __builtin_amdgcn_alignbyte(w1, w0, a), hi = __builtin_amdgcn_alignbyte(w2, w1, a);
+        // first four symbols in 32 bits, the rest and the bucket of the next symbol in 24 (every step a
+        // full-rate 24-bit multiply-add: the operands stay below 2^24), one 64-bit multiply-add joins them
         u32 k32 = lo & 255u;
-        k32 = k32 * uniq + ((lo >> 8) & 255u);
-        k32 = k32 * uniq + ((lo >> 16) & 255u);
-        k32 = k32 * uniq + (lo >> 24); // < uniq^4 <= 2^32
-        kk = k32;
-        u32 h = hi;
+        k32 = __umul24(k32, uniq) + ((lo >> 8) & 255u);
+        k32 = __umul24(k32, uniq) + ((lo >> 16) & 255u);
+        k32 = __umul24(k32, uniq) + (lo >> 24); // < uniq^4 <= 2^32 (the product's low 32 bits are exact)
+        u32 h = hi, klo = 0, M = 1; // M = uniq^(d0 - 4) * B <= 2^40 / uniq^4 <= 2^20 (uniq >= 33 on this path)
         for (u32 q = 4; q < d0; q++) {
-            kk = kk * uniq + (h & 255u);
+            klo = __umul24(klo, uniq) + (h & 255u);
+            M *= uniq;
             h >>= 8;
         }
         nxt = h & 255u;
+        const u32 Bq = xb & 255u;
+        if (Bq > 1u) {
+            klo = __umul24(klo, Bq) + ((nxt * (xb >> 8)) >> 16);
+            M *= Bq;
+        }
+        return (((u64)k32 * M + klo) << KEY_SHIFT) | (u64)i;
     } else {
         kk = 0;
         for (u32 q = 0; q < d0; q++) kk = kk * uniq + L.t[local + q];
