@@ -276,7 +276,11 @@ __device__ void ha_allocate(int *a, int len, int max_len) {
 
 // ------------------------------------------------------------------ code lengths (:107-135, :245-247)
 // grid (6, nb): sum the partial histograms, sort (freq<<9)|idx, allocate, scatter back
-__global__ __launch_bounds__(256) void k4_lengths(const u32 *__restrict__ mtflen,
+// NT threads per table: 256 when every table's workgroup is resident anyway (the histogram sum and the
+// rank sort then take 256 lanes), 64 for many blocks (-1: 16 000 tables; three of four waves leave before
+// the allocator, but until then they hold the slots other tables wait for)
+template <int NT>
+__global__ __launch_bounds__(NT) void k4_lengths(const u32 *__restrict__ mtflen,
                                                   const u32 *__restrict__ alphaArr,
                                                   const u32 *__restrict__ ntables,
                                                   const u32 *__restrict__ hpart,
@@ -290,7 +294,7 @@ __global__ __launch_bounds__(256) void k4_lengths(const u32 *__restrict__ mtflen
     __shared__ int sorted[HL];
     __shared__ int a[HL];
     K4_INIT
-    for (int j = threadIdx.x; j < HL; j += 256) {
+    for (int j = threadIdx.x; j < HL; j += NT) {
         u32 f = 0;
         if (j < alpha) {
             // all parts requested at once (a loop to `parts` waits for every load in turn)
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(256) void k4_lengths(const u32 *__restrict__ mtflen
     }
     __syncthreads();
     K4_MARK(0);
-    for (int j = threadIdx.x; j < alpha; j += 256) {
+    for (int j = threadIdx.x; j < alpha; j += NT) {
         int kj = key[j];
         int rnk = 0;
         for (int i = 0; i < alpha; i++) rnk += (key[i] < kj) ? 1 : 0;
@@ -892,8 +896,12 @@ void run_huffman(bz2hip_ctx *c, int nb, u32 maxmtf) {
         }
         {
             ProfScope ps(c, P_HUF_LENGTHS);
-            k4_lengths<<<dim3(MAX_TABLES, nb), 256, 0, c->stream>>>(B.mtflen, B.alpha, B.ntables,
-                                                                    B.hpart, B.hlen, B.hfreq);
+            if ((size_t)MAX_TABLES * nb > 2048) // more tables than 256-thread workgroups fit on the chip at once
+                k4_lengths<64><<<dim3(MAX_TABLES, nb), 64, 0, c->stream>>>(B.mtflen, B.alpha, B.ntables,
+                                                                           B.hpart, B.hlen, B.hfreq);
+            else
+                k4_lengths<256><<<dim3(MAX_TABLES, nb), 256, 0, c->stream>>>(B.mtflen, B.alpha, B.ntables,
+                                                                             B.hpart, B.hlen, B.hfreq);
             KCHECK();
         }
     }
