@@ -876,13 +876,14 @@ struct ShardJob {
     int rc = BZ2HIP_OK;
 };
 
-// Transfers between the callers' pageable buffers and the devices, and the workspace (re)allocations
-// next to them, are taken one worker at a time.  Seen on this stack (ROCm 7.2): with three workers
+// Transfers between the callers' pageable buffers and a device, and the workspace (re)allocations
+// next to them, are taken one worker at a time per GPU.  Seen on this stack (ROCm 7.2): with three workers
 // uploading at once, one worker's hipMemcpyAsync of 7.95 MB from pageable memory delivered its last
 // 613 280 bytes and left the 7 MiB before them untouched (the stream decoded to zeros there); twice in
 // ~40 runs of the test suite, only in the first process on a fresh machine.  The copies are short
 // next to the compression they feed; the kernels of the workers still overlap.
-static std::mutex g_pageable_mu;
+static std::mutex g_pageable_mu[BZ2HIP_MAX_DEVICES]; // per GPU: workers on different GPUs do not wait for each other
+static std::mutex &pageable_mu(const bz2hip_ctx *x) { return g_pageable_mu[(unsigned)x->device % BZ2HIP_MAX_DEVICES]; }
 
 struct ChainHop {
     std::mutex m;
@@ -919,7 +920,7 @@ static void shard_phase1(ShardJob &J, size_t r, size_t nw, const u8 *in, size_t 
             if (avail > WMAX) return fail(x, BZ2HIP_E_PARAM, "internal: shard larger than one window");
             int rc;
             {
-                std::lock_guard<std::mutex> g(g_pageable_mu);
+                std::lock_guard<std::mutex> g(pageable_mu(x));
                 if (ensure_staging(x, avail, bz2hip_compress_bound(avail))) uploaded = 0;
                 if (avail > uploaded) {
                     HIPCHK(hipMemcpyAsync(x->h_in + uploaded, in + J.lo + uploaded, avail - uploaded,
@@ -971,7 +972,7 @@ static void shard_phase2(ShardJob &J, u8 *out) {
     J.n_edges = 0;
     if (!J.nbits) return;
     J.rc = guarded(x, [&]() -> int {
-        std::lock_guard<std::mutex> g(g_pageable_mu);
+        std::lock_guard<std::mutex> g(pageable_mu(x));
         const u64 sh = J.off & 31;
         const size_t W = (size_t)((sh + J.nbits + 31) / 32);
         if (x->d_shift_cap < W * 4) {
